@@ -1,0 +1,310 @@
+"""ORACLE (test infrastructure, not product code): CPU restatement of Aurora's export rasteriser.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  Nothing under ``aurora_amd/`` imports it.
+
+Two layers:
+
+1. **Draw lists** -- the arguments the reference hands to QPainter, restated from
+   ``widgets/rt_widget.py``: ``drawlist_spectrum_linear`` (:934-940, :982-988),
+   ``drawlist_waveform_linear`` (:903-913), ``drawlist_particles`` (:990-1000).  These ARE pinned:
+   ``tests/golden/drawlists_*.npz`` were captured by driving the reference's own ``paint_frame``
+   with a recording painter (``tests/golden/make_golden.py``).
+
+2. **Coverage** -- which pixels a width-2, SquareCap, BevelJoin, non-antialiased QPen lights for those
+   draw calls.  Qt's raster engine is not part of the reference tree and the reference has no frame
+   goldens, so this layer is **parity unpinned** against Qt.  The rule implemented (and mirrored
+   bit-for-bit by the HIP kernels) is:
+
+   * a pixel is lit iff its centre ``(px + 0.5, py + 0.5)`` lies inside the stroke outline (closed set);
+   * stroke outline of a polyline = union of one rectangle per segment (half-width 1, extended by 1 px
+     beyond the first and last vertex = SquareCap) and one triangle per interior vertex on the outer
+     side of the turn (BevelJoin);
+   * integer primitives follow from that: ``drawLine(x0, ya, x0, yb)`` lights columns ``{x0-1, x0}``,
+     rows ``min(ya,yb)-1 .. max(ya,yb)``; ``drawPoint(x, y)`` lights the 2x2 block
+     ``{x-1, x} x {y-1, y}``; everything is clipped to the image;
+   * background is ``fillRect(0,0,w,h,(13,13,18))`` (rt_widget.py:829), pen colour is opaque.
+
+   Geometry is evaluated in float64 with the operation order below; the GPU kernels use the same
+   order with contraction disabled, so GPU == oracle is a bit-exact contract.
+
+Frames are represented through **column spans**: ``spans[W, K, 2]`` (int32) holds up to K half-open
+row intervals ``[r0, r1)`` per pixel column.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+BG = (13, 13, 18)           # rt_widget.py:829
+N_BARS = 80                 # rt_widget.py:935
+N_PARTICLES = 50            # rt_widget.py:991
+K_SPECTRUM = 2
+K_PARTICLES = 2
+K_WAVEFORM = 5
+_BIG = 1.0e6
+
+
+# --------------------------------------------------------------------------- draw lists
+
+def spectrum_bar_heights(spectrum: np.ndarray, energy: float, h: int) -> np.ndarray:
+    """rt_widget.py:938-940, :985-986 -> bh[80] (python ints)."""
+    spec = spectrum[:N_BARS]
+    mx = float(np.max(spec)) if np.max(spec) > 0 else 1.0
+    spec = spec / mx
+    bh = np.empty(N_BARS, dtype=np.int64)
+    for i in range(N_BARS):
+        v = float(spec[i])
+        bh[i] = int(v * (h - 10) * (0.4 + 0.6 * energy))
+    return bh
+
+
+def drawlist_spectrum_linear(spectrum, energy, w, h):
+    """-> int64[80,4] rows (x0, h-5, x0, h-5-bh) as passed to ``p.drawLine`` (rt_widget.py:983-988)."""
+    bh = spectrum_bar_heights(spectrum, energy, h)
+    bar_w = max(1, int(w / N_BARS))
+    out = np.empty((N_BARS, 4), dtype=np.int64)
+    for i in range(N_BARS):
+        x0 = i * bar_w
+        out[i] = (x0, h - 5, x0, h - 5 - int(bh[i]))
+    return out
+
+
+def waveform_col2samp(w: int, n: int = 1024) -> np.ndarray:
+    """rt_widget.py:908 ``i = int((x / max(1, w - 1)) * (n - 1))`` for every column (index map)."""
+    out = np.empty(w, dtype=np.int32)
+    for x in range(w):
+        out[x] = int((x / max(1, w - 1)) * (n - 1))
+    return out
+
+
+def drawlist_waveform_linear(samples, energy, w, h):
+    """-> float64[w] path y per integer x (rt_widget.py:904-913).
+
+    ``samples[i] * amp`` is np.float32 * python float -> float32 under NEP 50, and
+    ``mid - <float32>`` stays float32, so y is a float32 value widened by ``float()``.
+    """
+    n = len(samples)
+    amp = 0.45 * (h / 2) * (0.5 + energy)
+    mid = h / 2.0
+    idx = waveform_col2samp(w, n)
+    ys = np.empty(w, dtype=np.float64)
+    for x in range(w):
+        ys[x] = float(mid - samples[idx[x]] * amp)
+    return ys
+
+
+def drawlist_particles(spectrum, w, h):
+    """-> int64[50,2] (x, y) as passed to ``p.drawPoint`` (rt_widget.py:994-1000)."""
+    spec = spectrum[:N_PARTICLES]
+    spec = spec / (np.max(spec) + 1e-6)
+    out = np.empty((N_PARTICLES, 2), dtype=np.int64)
+    for i in range(N_PARTICLES):
+        v = float(spec[i])
+        x = int((i + 0.5) / N_PARTICLES * w)
+        y = int(h / 2 + (v - 0.5) * h * 0.6)
+        out[i] = (x, y)
+    return out
+
+
+# --------------------------------------------------------------------------- spans
+
+def _clip_rows(r0, r1, h):
+    r0 = np.clip(r0, 0, h)
+    r1 = np.clip(r1, 0, h)
+    empty = r1 <= r0
+    r0 = np.where(empty, 0, r0)
+    r1 = np.where(empty, 0, r1)
+    return r0, r1
+
+
+def spans_spectrum_linear(spectrum, energy, w, h):
+    """Column spans of the 80 bars: slot 0 = bar whose x0 == px, slot 1 = bar whose x0 - 1 == px."""
+    dl = drawlist_spectrum_linear(spectrum, energy, w, h)
+    spans = np.zeros((w, K_SPECTRUM, 2), dtype=np.int32)
+    for i in range(N_BARS):
+        x0, ya, _, yb = (int(v) for v in dl[i])
+        r0 = min(ya, yb) - 1
+        r1 = max(ya, yb) + 1
+        r0 = max(0, min(h, r0))
+        r1 = max(0, min(h, r1))
+        if r1 <= r0:
+            r0 = r1 = 0
+        if 0 <= x0 < w:
+            spans[x0, 0] = (r0, r1)
+        if 0 <= x0 - 1 < w:
+            spans[x0 - 1, 1] = (r0, r1)
+    return spans
+
+
+def spans_particles(spectrum, w, h):
+    """Column spans of the 50 points: slot 0 = point whose x == px, slot 1 = point whose x - 1 == px."""
+    dl = drawlist_particles(spectrum, w, h)
+    spans = np.zeros((w, K_PARTICLES, 2), dtype=np.int32)
+    for i in range(N_PARTICLES):
+        x, y = int(dl[i, 0]), int(dl[i, 1])
+        r0 = max(0, min(h, y - 1))
+        r1 = max(0, min(h, y + 1))
+        if r1 <= r0:
+            r0 = r1 = 0
+        if 0 <= x < w:
+            spans[x, 0] = (r0, r1)
+        if 0 <= x - 1 < w:
+            spans[x - 1, 1] = (r0, r1)
+    return spans
+
+
+def _rows_from_interval(ylo, yhi, valid, h):
+    """Rows whose centre py + 0.5 lies in [ylo, yhi]; float64, clamped before the int conversion."""
+    ylo = np.minimum(np.maximum(ylo, -_BIG), _BIG)
+    yhi = np.minimum(np.maximum(yhi, -_BIG), _BIG)
+    r0 = np.ceil(ylo - 0.5).astype(np.int64)
+    r1 = np.floor(yhi - 0.5).astype(np.int64) + 1
+    r0, r1 = _clip_rows(r0, r1, h)
+    r0 = np.where(valid, r0, 0)
+    r1 = np.where(valid, r1, 0)
+    empty = r1 <= r0
+    return np.where(empty, 0, r0).astype(np.int32), np.where(empty, 0, r1).astype(np.int32)
+
+
+def _segment_interval(Y, seg, px, w):
+    """y-interval of segment ``seg``'s stroke rectangle on the vertical line x = px + 0.5.
+
+    seg, px: int arrays of equal shape.  Returns (ylo, yhi, valid).
+    """
+    nseg = w - 1
+    ok = (seg >= 0) & (seg < nseg)
+    s = np.clip(seg, 0, max(0, nseg - 1))
+    y0 = Y[s]
+    y1 = Y[np.minimum(s + 1, w - 1)]
+    dy = y1 - y0
+    L2 = 1.0 + dy * dy
+    L = np.sqrt(L2)
+    rx = (px + 0.5) - s
+    c = rx * dy
+    tlo = c - L
+    thi = c + L
+    s0L = np.where(s == 0, -L, 0.0)
+    s1L = np.where(s == nseg - 1, L2 + L, L2)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        qa = (s0L - rx) / dy
+        qb = (s1L - rx) / dy
+    pos = dy > 0.0
+    neg = dy < 0.0
+    flat = ~(pos | neg)
+    slo = np.where(pos, qa, np.where(neg, qb, -_BIG))
+    shi = np.where(pos, qb, np.where(neg, qa, _BIG))
+    flat_in = (s0L <= rx) & (rx <= s1L)
+    ok = ok & (~flat | flat_in)
+    lo = np.maximum(tlo, slo)
+    hi = np.minimum(thi, shi)
+    return y0 + lo, y0 + hi, ok
+
+
+def _bevel_interval(Y, vtx, px, w):
+    """y-interval of the BevelJoin triangle at interior vertex ``vtx`` on the line x = px + 0.5."""
+    ok = (vtx >= 1) & (vtx <= w - 2)
+    v = np.clip(vtx, 1, max(1, w - 2))
+    yv = Y[v]
+    dyA = yv - Y[v - 1]
+    dyB = Y[np.minimum(v + 1, w - 1)] - yv
+    LA = np.sqrt(1.0 + dyA * dyA)
+    LB = np.sqrt(1.0 + dyB * dyB)
+    cr = dyB - dyA
+    ok = ok & (cr != 0.0)
+    sg = np.where(cr > 0.0, -1.0, 1.0)
+    u1 = (sg * (-dyA)) / LA
+    w1 = sg / LA
+    u2 = (sg * (-dyB)) / LB
+    w2 = sg / LB
+    uc = (px + 0.5) - v
+    ymin = np.full(uc.shape, _BIG)
+    ymax = np.full(uc.shape, -_BIG)
+    hit = np.zeros(uc.shape, dtype=bool)
+    for (ua, ya, ub, yb) in ((0.0, 0.0, u1, w1), (0.0, 0.0, u2, w2), (u1, w1, u2, w2)):
+        ua = np.broadcast_to(np.asarray(ua, dtype=np.float64), uc.shape)
+        ya = np.broadcast_to(np.asarray(ya, dtype=np.float64), uc.shape)
+        lo_u = np.minimum(ua, ub)
+        hi_u = np.maximum(ua, ub)
+        cross = (ua != ub) & (lo_u <= uc) & (uc <= hi_u)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            yc = ya + ((uc - ua) * (yb - ya)) / (ub - ua)
+        ymin = np.where(cross & (yc < ymin), yc, ymin)
+        ymax = np.where(cross & (yc > ymax), yc, ymax)
+        hit = hit | cross
+    ok = ok & hit
+    return yv + ymin, yv + ymax, ok
+
+
+def spans_waveform_linear(samples, energy, w, h):
+    """Column spans of the width-2 SquareCap/BevelJoin polyline through (x, y_x), x = 0..w-1.
+
+    Slots: [segment px-1, segment px, segment px+1, bevel at vertex px, bevel at vertex px+1].
+    """
+    Y = drawlist_waveform_linear(samples, energy, w, h)
+    return spans_polyline(Y, w, h)
+
+
+def spans_polyline(Y, w, h):
+    Y = np.asarray(Y, dtype=np.float64)
+    px = np.arange(w, dtype=np.int64)
+    spans = np.zeros((w, K_WAVEFORM, 2), dtype=np.int32)
+    if w < 2:
+        return spans
+    for slot, seg in enumerate((px - 1, px, px + 1)):
+        ylo, yhi, ok = _segment_interval(Y, seg, px, w)
+        r0, r1 = _rows_from_interval(ylo, yhi, ok, h)
+        spans[:, slot, 0] = r0
+        spans[:, slot, 1] = r1
+    for slot, vtx in enumerate((px, px + 1)):
+        ylo, yhi, ok = _bevel_interval(Y, vtx, px, w)
+        r0, r1 = _rows_from_interval(ylo, yhi, ok, h)
+        spans[:, 3 + slot, 0] = r0
+        spans[:, 3 + slot, 1] = r1
+    return spans
+
+
+# --------------------------------------------------------------------------- frames
+
+def rasterize_spans(spans, pen_rgb, w, h, bg=BG):
+    """Background fill + pen colour on every (column, row) inside a span -> uint8[h, w, 3]."""
+    frame = np.empty((h, w, 3), dtype=np.uint8)
+    frame[:] = np.asarray(bg, dtype=np.uint8)
+    pen = np.asarray(pen_rgb, dtype=np.uint8)
+    cols = np.nonzero((spans[:, :, 1] > spans[:, :, 0]).any(axis=1))[0]
+    for px in cols:
+        for k in range(spans.shape[1]):
+            r0, r1 = int(spans[px, k, 0]), int(spans[px, k, 1])
+            if r1 > r0:
+                frame[r0:r1, px] = pen
+    return frame
+
+
+def mode_kind(mode: str) -> str:
+    """Dispatch of rt_widget.py:840-849."""
+    if mode.startswith("Waveform"):
+        return "waveform_circular" if "Circular" in mode else "waveform_linear"
+    if mode.startswith("Spectrum"):
+        return "spectrum_radial" if "Radial" in mode else "spectrum_linear"
+    return "particles"
+
+
+def frame_spans(mode, samples, spectrum, energy, w, h):
+    kind = mode_kind(mode)
+    if kind == "spectrum_linear":
+        return spans_spectrum_linear(spectrum, energy, w, h)
+    if kind == "waveform_linear":
+        return spans_waveform_linear(samples, energy, w, h)
+    if kind == "particles":
+        return spans_particles(spectrum, w, h)
+    raise NotImplementedError(f"oracle rasteriser does not cover mode {mode!r}")
+
+
+def render_frame(mode, samples, spectrum, energy, pen_rgb, w, h):
+    """One exported frame (rt_widget.py:821-852) -> uint8[h, w, 3]."""
+    return rasterize_spans(frame_spans(mode, samples, spectrum, energy, w, h), pen_rgb, w, h)
+
+
+def psnr(a: np.ndarray, b: np.ndarray) -> float:
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float(np.mean(d * d))
+    return float('inf') if mse == 0.0 else 10.0 * np.log10(255.0 * 255.0 / mse)

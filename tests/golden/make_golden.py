@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box).
+The reference has no tests or golden files of its own, so these fixtures
+are produced by importing its modules and driving them with seeded synthetic audio:
+
+* ``audio.analysis.Analyzer``                       -- imported as is (numpy/scipy only);
+* ``export.exporter.QPainterOffscreenRenderer``     -- imported with two stand-in modules for
+  packages that are not installed here: ``soundfile`` (an in-memory array with
+  seek/read/len/samplerate) and ``PySide6`` (a *recording* QPainter/QPainterPath/QPen/QColor that
+  stores the arguments of every draw call instead of rasterising).  ``_read_frame`` and
+  ``RTVisualizerWidget.paint_frame`` therefore execute the reference's own code; what is captured
+  is (a) the analysis outputs and (b) the draw lists.  No pixel is produced: Qt's raster engine
+  is not available, so pixel coverage stays "parity unpinned" (see oracle/raster_ref.py).
+
+Usage:  python tests/golden/make_golden.py        (writes tests/golden/*.npz)
+Fixtures are data only (inputs + expected outputs).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("AURORA_REFERENCE", "/root/reference")
+
+sys.path.insert(0, REPO)
+from aurora_amd import synth  # noqa: E402  (input generator only)
+
+# ----------------------------------------------------------------------------- stand-ins
+
+_AUDIO = {}      # path -> (array [n] or [n, C] float32, samplerate)
+
+
+class _SoundFile:
+    def __init__(self, path, mode='r'):
+        if path not in _AUDIO:
+            raise RuntimeError(f"unknown in-memory audio {path!r}")
+        self._data, self.samplerate = _AUDIO[path]
+        self._pos = 0
+
+    def __len__(self):
+        return int(self._data.shape[0])
+
+    def seek(self, frame):
+        self._pos = int(frame)
+
+    def read(self, frames, dtype='float32', always_2d=False):
+        end = min(len(self), self._pos + int(frames))
+        y = np.array(self._data[self._pos:end], dtype=np.float32, copy=True)
+        self._pos = end
+        return y
+
+
+class QColor:
+    HexArgb = 1
+
+    def __init__(self, *a):
+        self._valid = True
+        if len(a) == 1 and isinstance(a[0], QColor):
+            self.r, self.g, self.b, self.a = a[0].r, a[0].g, a[0].b, a[0].a
+        elif len(a) == 1 and isinstance(a[0], str):
+            s = a[0].lstrip('#')
+            try:
+                if len(s) == 8:
+                    self.a, self.r, self.g, self.b = (int(s[i:i + 2], 16) for i in (0, 2, 4, 6))
+                elif len(s) == 6:
+                    self.r, self.g, self.b = (int(s[i:i + 2], 16) for i in (0, 2, 4))
+                    self.a = 255
+                else:
+                    raise ValueError
+            except ValueError:
+                self.r = self.g = self.b = 0
+                self.a = 255
+                self._valid = False
+        elif len(a) >= 3:
+            self.r, self.g, self.b = int(a[0]), int(a[1]), int(a[2])
+            self.a = int(a[3]) if len(a) > 3 else 255
+        else:
+            self.r = self.g = self.b = 0
+            self.a = 255
+            self._valid = False
+
+    def red(self): return self.r
+    def green(self): return self.g
+    def blue(self): return self.b
+    def alpha(self): return self.a
+    def isValid(self): return self._valid
+    def setAlpha(self, a): self.a = int(a)
+    def name(self, *_): return "#%02x%02x%02x%02x" % (self.a, self.r, self.g, self.b)
+    def tup(self): return (self.r, self.g, self.b, self.a)
+
+
+class QPen:
+    def __init__(self, color=None):
+        self.color = QColor(color) if color is not None else QColor(0, 0, 0)
+        self.width = 1
+        self.cap = "SquareCap"      # Qt default
+        self.join = "BevelJoin"     # Qt default
+
+    def setWidth(self, w): self.width = int(w)
+    def setCapStyle(self, c): self.cap = c
+    def setJoinStyle(self, j): self.join = j
+
+
+class QPainterPath:
+    def __init__(self):
+        self.ops = []
+
+    def moveTo(self, x, y): self.ops.append(("M", float(x), float(y)))
+    def lineTo(self, x, y): self.ops.append(("L", float(x), float(y)))
+    def closeSubpath(self): self.ops.append(("Z", 0.0, 0.0))
+
+
+class QImage:
+    Format_RGB888 = 13
+
+    def __init__(self, *a):
+        self.args = a
+        self.calls = []
+
+    def isNull(self): return len(self.args) < 2
+
+
+class QPainter:
+    Antialiasing = 1
+    SmoothPixmapTransform = 2
+    CompositionMode_Plus = 12
+    CompositionMode_Multiply = 13
+
+    def __init__(self, device=None):
+        self.device = device
+        self.calls = device.calls if device is not None else []
+        self.hints = set()
+
+    def isActive(self): return True
+    def end(self): self.calls.append(("end",))
+
+    def fillRect(self, *a):
+        col = a[-1]
+        self.calls.append(("fillRect", tuple(a[:-1]), col.tup()))
+
+    def setPen(self, pen):
+        if isinstance(pen, QColor):
+            pen = QPen(pen)
+        self.calls.append(("setPen", pen.color.tup(), pen.width, pen.cap, pen.join))
+
+    def setRenderHint(self, hint, on=True):
+        (self.hints.add if on else self.hints.discard)(hint)
+        self.calls.append(("setRenderHint", hint, bool(on)))
+
+    def drawLine(self, x1, y1, x2, y2): self.calls.append(("drawLine", x1, y1, x2, y2))
+    def drawPoint(self, x, y): self.calls.append(("drawPoint", x, y))
+    def drawPath(self, path): self.calls.append(("drawPath", list(path.ops)))
+    def fillPath(self, path, col): self.calls.append(("fillPath", list(path.ops), col.tup()))
+    def setClipPath(self, path): self.calls.append(("setClipPath", list(path.ops)))
+    def save(self): self.calls.append(("save",))
+    def restore(self): self.calls.append(("restore",))
+
+    def __getattr__(self, name):        # anything else: record the call
+        def _rec(*a, **k):
+            self.calls.append((name, "unrecorded-args"))
+        return _rec
+
+
+class _QWidget:
+    def __init__(self, *a, **k): pass
+    def update(self): pass
+    def setMinimumSize(self, *a): pass
+    def width(self): return 0
+    def height(self): return 0
+    def rect(self): return None
+
+
+class _Qt:
+    PreciseTimer = 0
+    RoundCap = "RoundCap"
+    RoundJoin = "RoundJoin"
+    SquareCap = "SquareCap"
+    KeepAspectRatio = 1
+    IgnoreAspectRatio = 0
+    KeepAspectRatioByExpanding = 2
+    SmoothTransformation = 1
+
+
+def _install_stand_ins():
+    sf = types.ModuleType("soundfile")
+    sf.SoundFile = _SoundFile
+    sys.modules["soundfile"] = sf
+
+    def _dummy(name):
+        return type(name, (), {"__init__": lambda self, *a, **k: None})
+
+    pkg = types.ModuleType("PySide6")
+    pkg.__path__ = []
+    core = types.ModuleType("PySide6.QtCore")
+    core.Qt = _Qt
+    for n in ("QTimer", "QSize", "QRect", "QThread"):
+        setattr(core, n, _dummy(n))
+    core.QCoreApplication = type("QCoreApplication", (), {"instance": staticmethod(lambda: None)})
+    gui = types.ModuleType("PySide6.QtGui")
+    gui.QPainter, gui.QColor, gui.QPen, gui.QImage, gui.QPainterPath = QPainter, QColor, QPen, QImage, QPainterPath
+    for n in ("QPixmap", "QTransform", "QSurfaceFormat"):
+        setattr(gui, n, _dummy(n))
+    wid = types.ModuleType("PySide6.QtWidgets")
+    wid.QWidget = _QWidget
+    wid.QApplication = _dummy("QApplication")
+    pkg.QtCore, pkg.QtGui, pkg.QtWidgets = core, gui, wid
+    sys.modules.update({"PySide6": pkg, "PySide6.QtCore": core, "PySide6.QtGui": gui, "PySide6.QtWidgets": wid})
+
+
+# ----------------------------------------------------------------------------- capture
+
+def _track(kind, n, sr, channels, seed=1234):
+    a = synth.make(kind, n, sr, channels=max(1, channels), seed=seed)
+    return a[:, 0].copy() if channels == 0 else a          # channels == 0 -> 1-D mono file
+
+
+def capture_analysis(name, kind, n, sr, fps, channels, sensitivity=1.0):
+    """Reference _read_frame + Analyzer over a whole synthetic track."""
+    from export.exporter import QPainterOffscreenRenderer
+    audio = _track(kind, n, sr, channels)
+    path = f"mem://{name}"
+    _AUDIO[path] = (audio, sr)
+    r = QPainterOffscreenRenderer(64, 64, "Spectrum - Linear", (0.2, 0.8, 1.0), sensitivity, fps, path)
+    total = int(np.ceil(r.duration * fps))                    # exporter.py:536
+    samples = np.zeros((total, 1024), np.float32)
+    logspec = np.zeros((total, 1025), np.float32)
+    flux = np.zeros(total, np.float64)
+    energy = np.zeros(total, np.float64)
+    pen = np.zeros((total, 3), np.uint8)
+    phase = np.zeros(total, np.float64)
+    v = r._view
+    for i in range(total):
+        t = i / fps                                           # exporter.py:539
+        s, spec = r._read_frame(t)
+        samples[i], logspec[i], flux[i] = s, spec, r._feeder._flux
+        img = v.render_frame_to_qimage(64, 64, s, spec)       # runs paint_frame -> energy, colour, phase
+        fill = [c for c in img.calls if c[0] == "fillRect"][0]
+        assert fill[2][:3] == (13, 13, 18)
+        sp = [c for c in img.calls if c[0] == "setPen"][0]
+        pen[i] = sp[1][:3]
+        phase[i] = v._phase
+        energy[i] = float(np.clip(np.mean(np.abs(s)) * v.waveform_sensitivity, 0.0, 1.0))
+    hop = max(1, int(sr / fps))
+    np.savez_compressed(os.path.join(HERE, f"analysis_{name}.npz"), audio=audio, sample_rate=sr, fps=fps,
+                        sensitivity=sensitivity, hop=hop, samples=samples, logspec=logspec, flux_smooth=flux,
+                        energy=energy, pen_rgb=pen, phase=phase)
+    print(f"analysis_{name}: {total} frames, hop {hop}, audio {audio.shape}")
+    return audio
+
+
+def _path_xy(ops):
+    return np.array([(o[1], o[2]) for o in ops if o[0] in "ML"], dtype=np.float64)
+
+
+def capture_drawlists(name, kind, n, sr, fps, sizes, frames):
+    """Reference paint_frame draw calls for the three linear modes (and Radial path vertices)."""
+    from export.exporter import QPainterOffscreenRenderer
+    audio = _track(kind, n, sr, 2)
+    path = f"mem://dl_{name}"
+    _AUDIO[path] = (audio, sr)
+    out = dict(audio=audio, sample_rate=sr, fps=fps, frames=np.asarray(frames), sizes=np.asarray(sizes))
+    for mode, tag in (("Spectrum - Linear", "spec"), ("Waveform - Linear", "wave"), ("Particles", "part"),
+                      ("Spectrum - Radial", "radial")):
+        for (w, h) in sizes:
+            r = QPainterOffscreenRenderer(w, h, mode, (0.2, 0.8, 1.0), 1.0, fps, path)
+            total = int(np.ceil(r.duration * fps))
+            keep = set(int(f) for f in frames)
+            for i in range(total):
+                s, spec = r._read_frame(i / fps)
+                img = r._view.render_frame_to_qimage(w, h, s, spec)
+                if i not in keep:
+                    continue
+                calls = img.calls
+                key = f"{tag}_{w}x{h}_f{i}"
+                sp = [c for c in calls if c[0] == "setPen"][0]
+                assert sp[2] == 2 and sp[3] == "SquareCap" and sp[4] == "BevelJoin", sp
+                assert not any(c[0] == "setRenderHint" for c in calls) or tag == "radial"
+                out[key + "_pen"] = np.asarray(sp[1][:3], np.uint8)
+                out[key + "_samples"] = s.copy()
+                out[key + "_spectrum"] = spec.copy()
+                if tag == "spec":
+                    out[key + "_lines"] = np.asarray([c[1:] for c in calls if c[0] == "drawLine"], np.int64)
+                elif tag == "part":
+                    out[key + "_points"] = np.asarray([c[1:] for c in calls if c[0] == "drawPoint"], np.int64)
+                elif tag == "wave":
+                    dp = [c for c in calls if c[0] == "drawPath"]
+                    assert len(dp) == 1
+                    out[key + "_path"] = _path_xy(dp[0][1])
+                else:
+                    dp = [c for c in calls if c[0] == "drawPath"]
+                    out[key + "_path"] = _path_xy(dp[0][1])
+                    cp = [c for c in calls if c[0] == "setClipPath"]
+                    out[key + "_clip"] = _path_xy(cp[0][1])
+                    out[key + "_calls"] = np.asarray([c[0] for c in calls])
+    np.savez_compressed(os.path.join(HERE, f"drawlists_{name}.npz"), **out)
+    print(f"drawlists_{name}: {len(out)} arrays")
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit(f"reference not found at {REF}; fixtures can only be regenerated in the build container")
+    _install_stand_ins()
+    sys.path.insert(0, REF)
+    # analysis fixtures: the three hop regimes of SURVEY 8(c) (+ mono, + ragged EOF lengths)
+    capture_analysis("sweep_44k1_30", "sweep", 44100 + 777, 44100, 30, 2)       # hop 1470 > 1024
+    capture_analysis("pink_48k_60", "pink", 47000, 48000, 60, 2)                # hop 800 (+224 zeros), short last read
+    capture_analysis("pink_44k1_60", "pink", 22050 + 123, 44100, 60, 2)         # hop 735 (odd)
+    capture_analysis("sweep_48k_60_mono", "sweep", 24000 + 5, 48000, 60, 0)     # 1-D mono file
+    capture_analysis("pink_48k_24_sens", "pink", 30000, 48000, 24, 2, sensitivity=2.5)   # hop 2000, sensitivity != 1
+    capture_analysis("tiny_48k_60", "pink", 500, 48000, 60, 2)                  # shorter than one hop
+    capture_drawlists("pink_48k_60", "pink", 12000, 48000, 60,
+                      sizes=[(1280, 720), (1920, 1080), (3840, 2160)], frames=[0, 1, 2, 5, 9, 13, 14])
+    capture_drawlists("sweep_44k1_30", "sweep", 22050, 44100, 30,
+                      sizes=[(1280, 720), (1000, 562)], frames=[0, 3, 7, 14])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+"""Pin the oracle (oracle/*.py) to fixtures captured from the reference itself (tests/golden/make_golden.py).
+
+CPU-only.  Analysis outputs must be BIT-EXACT (same numpy ops, same order); draw lists must be exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_analysis_names, load_golden
+from oracle import analysis_ref as A
+from oracle import raster_ref as R
+
+
+def _audio(g):
+    a = g["audio"]
+    return a
+
+
+@pytest.mark.parametrize("name", golden_analysis_names())
+def test_analysis_bit_exact(name):
+    g = load_golden("analysis_" + name)
+    audio, sr, fps = _audio(g), int(g["sample_rate"]), int(g["fps"])
+    out = A.analyze_track(audio, sr, fps, sensitivity=float(g["sensitivity"]))
+    assert out["hop"] == int(g["hop"])
+    assert out["samples"].shape == g["samples"].shape
+    assert np.array_equal(out["samples"], g["samples"])
+    assert np.array_equal(out["logspec"], g["logspec"])
+    assert out["logspec"].dtype == np.float32
+    assert np.array_equal(out["flux_smooth"], g["flux_smooth"])
+    assert np.array_equal(out["energy"], g["energy"])
+
+
+@pytest.mark.parametrize("name", golden_analysis_names())
+def test_scan_state_bit_exact(name):
+    g = load_golden("analysis_" + name)
+    rgb, _ = A.amp_to_color_track(g["energy"])
+    assert np.array_equal(rgb, g["pen_rgb"])
+    assert np.array_equal(A.phase_track(g["energy"]), g["phase"])
+
+
+def test_known_answer_from_survey():
+    # observed by importing the reference Analyzer
+    x = np.random.default_rng(0).standard_normal(1024).astype(np.float32)
+    an = A.AnalyzerRef(48000, 2048)
+    _, f1 = an.compute(x)
+    s2, f2 = an.compute(x)
+    assert f1 == 1.735073932926829
+    assert f2 == 2.37437275152439
+    assert np.allclose(s2[:4], [3.939069, 3.587926, 3.061712, 2.5850947], rtol=0, atol=5e-7)
+    assert s2.dtype == np.float32 and s2.shape == (1025,) and isinstance(f2, float)
+
+
+def test_window_formula_equals_scipy():
+    from scipy.signal import get_window
+    assert np.array_equal(A.hann_window_f32(2048), get_window('hann', 2048, fftbins=True).astype(np.float32))
+
+
+def test_small_block_branch():
+    # audio/analysis.py:21-23 (n < hop): np.roll branch
+    an = A.AnalyzerRef()
+    x = np.arange(100, dtype=np.float32)
+    an.compute(x)
+    assert np.array_equal(an.buffer[-100:], x) and not an.buffer[:-100].any()
+
+
+def test_pos_rule_known_counts():
+    # frames whose pos is one sample below the exact rational
+    hop, total, pos = A.frame_plan(48000 * 240, 48000, 60)
+    exact = (np.arange(total, dtype=np.int64) * 48000) // 60
+    assert hop == 800 and total == 14400
+    assert int(np.sum(pos == exact - 1)) == 744 and int(np.sum((pos != exact) & (pos != exact - 1))) == 0
+    hop, total, pos = A.frame_plan(44100 * 30, 44100, 30)
+    exact = (np.arange(total, dtype=np.int64) * 44100) // 30
+    assert hop == 1470 and total == 900 and int(np.sum(pos == exact - 1)) == 63
+
+
+DL = ["drawlists_pink_48k_60", "drawlists_sweep_44k1_30"]
+
+
+def _keys(g, tag):
+    return sorted(k[:-len("_pen")] for k in g.files if k.startswith(tag + "_") and k.endswith("_pen"))
+
+
+def _wh(key):
+    w, h = key.split("_")[1].split("x")
+    return int(w), int(h)
+
+
+@pytest.mark.parametrize("fixture", DL)
+def test_drawlist_spectrum(fixture):
+    g = load_golden(fixture)
+    keys = _keys(g, "spec")
+    assert keys
+    for k in keys:
+        w, h = _wh(k)
+        s = g[k + "_samples"]
+        e = A.frame_energy(s)
+        assert np.array_equal(R.drawlist_spectrum_linear(g[k + "_spectrum"], e, w, h), g[k + "_lines"]), k
+
+
+@pytest.mark.parametrize("fixture", DL)
+def test_drawlist_particles(fixture):
+    g = load_golden(fixture)
+    keys = _keys(g, "part")
+    assert keys
+    for k in keys:
+        w, h = _wh(k)
+        assert np.array_equal(R.drawlist_particles(g[k + "_spectrum"], w, h), g[k + "_points"]), k
+
+
+@pytest.mark.parametrize("fixture", DL)
+def test_drawlist_waveform(fixture):
+    g = load_golden(fixture)
+    keys = _keys(g, "wave")
+    assert keys
+    for k in keys:
+        w, h = _wh(k)
+        s = g[k + "_samples"]
+        e = A.frame_energy(s)
+        path = g[k + "_path"]
+        assert path.shape == (w, 2)
+        assert np.array_equal(path[:, 0], np.arange(w, dtype=np.float64))
+        assert np.array_equal(R.drawlist_waveform_linear(s, e, w, h), path[:, 1]), k
+
+
+@pytest.mark.parametrize("fixture", DL)
+def test_pen_colour_sequence(fixture):
+    # pen colour of the kept frames == oracle EMA colour over the whole prefix of the track
+    g = load_golden(fixture)
+    audio, sr, fps = g["audio"], int(g["sample_rate"]), int(g["fps"])
+    out = A.analyze_track(audio, sr, fps)
+    rgb, _ = A.amp_to_color_track(out["energy"])
+    for k in _keys(g, "spec"):
+        f = int(k.split("_f")[-1])
+        assert np.array_equal(rgb[f], g[k + "_pen"]), k
+        assert np.array_equal(out["samples"][f], g[k + "_samples"])
+        assert np.array_equal(out["logspec"][f], g[k + "_spectrum"])

@@ -1,0 +1,149 @@
+"""ctypes binding of libaurora_hip.so (include/aurora_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, this module
+raises.  Build the library with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C aurora_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaurora_hip.so")
+
+ABI_VERSION = 1
+
+# every symbol include/aurora_hip.h declares (tests check the library exports exactly these)
+SYMBOLS = (
+    "aur_version", "aur_last_error", "aur_device_count", "aur_create", "aur_destroy", "aur_get_window",
+    "aur_stft_frames", "aur_stft_buffer", "aur_scan_frames",
+    "aur_spans_spectrum_linear", "aur_spans_particles", "aur_spans_waveform_linear", "aur_raster_spans",
+    "aur_host_alloc", "aur_host_free", "aur_readback_async", "aur_stream_synchronize",
+)
+
+K_SPECTRUM, K_PARTICLES, K_WAVEFORM = 2, 2, 5
+FFT_SIZE, BLOCK, NBINS = 2048, 1024, 1025
+
+
+class AuroraHipError(RuntimeError):
+    pass
+
+
+class ScanParams(C.Structure):
+    """struct aur_scan_params (include/aurora_hip.h). Defaults = RTVisualizerWidget/Analyzer defaults."""
+    _fields_ = [
+        ("sensitivity", C.c_double),
+        ("amp_alpha", C.c_double),
+        ("grad_min", C.c_double),
+        ("grad_max", C.c_double),
+        ("grad_curve", C.c_int),
+        ("grad_a", C.c_uint8 * 4),
+        ("grad_b", C.c_uint8 * 4),
+        ("flux_alpha", C.c_double),
+        ("amp_ema0", C.c_double),
+        ("flux_smooth0", C.c_double),
+        ("phase0", C.c_double),
+    ]
+
+    CURVES = {"linear": 0, "ease-in": 1, "ease-out": 2, "smoothstep": 3}
+
+    @classmethod
+    def defaults(cls, sensitivity=1.0):
+        p = cls()
+        p.sensitivity = max(0.05, float(sensitivity))     # widgets/rt_widget.py:142
+        p.amp_alpha = 0.2                                  # rt_widget.py:57
+        p.grad_min, p.grad_max = 0.0, 1.0                  # rt_widget.py:54-55
+        p.grad_curve = 0                                   # rt_widget.py:53
+        p.grad_a[:] = (32, 255, 255, 0)                    # rt_widget.py:51
+        p.grad_b[:] = (255, 0, 255, 0)                     # rt_widget.py:52
+        p.flux_alpha = 0.9                                 # audio/analysis.py:12
+        p.amp_ema0 = p.flux_smooth0 = p.phase0 = 0.0
+        return p
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _declare(lib):
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.aur_version.restype = i32
+    lib.aur_version.argtypes = []
+    lib.aur_last_error.restype = C.c_char_p
+    lib.aur_last_error.argtypes = []
+    lib.aur_device_count.argtypes = [C.POINTER(i32)]
+    lib.aur_create.argtypes = [i32, C.POINTER(vp)]
+    lib.aur_destroy.restype = None
+    lib.aur_destroy.argtypes = [vp]
+    lib.aur_get_window.argtypes = [vp, vp]
+    lib.aur_stft_frames.argtypes = [vp, vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.aur_stft_buffer.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.aur_scan_frames.argtypes = [vp, vp, vp, i32, C.POINTER(ScanParams), vp, vp, vp, vp, vp, vp]
+    lib.aur_spans_spectrum_linear.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.aur_spans_particles.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.aur_spans_waveform_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.aur_raster_spans.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp]
+    lib.aur_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    lib.aur_host_free.argtypes = [vp]
+    lib.aur_readback_async.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.aur_stream_synchronize.argtypes = [vp, vp]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("aur_last_error", "aur_destroy"):
+            fn.restype = i32
+
+
+def load():
+    """Load (once) and return the ctypes library.  Raises AuroraHipError if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise AuroraHipError(
+                    f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
+                    "aurora_amd has no CPU fallback")
+            lib = C.CDLL(LIB_PATH)
+            missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+            if missing:
+                raise AuroraHipError(f"{LIB_PATH} lacks symbols {missing}")
+            _declare(lib)
+            if lib.aur_version() != ABI_VERSION:
+                raise AuroraHipError(f"ABI version {lib.aur_version()} != expected {ABI_VERSION}")
+            _lib = lib
+        return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().aur_last_error().decode("utf-8", "replace")
+        raise AuroraHipError(f"{what or 'aurora_hip call'} failed (code {rc}): {msg}")
+
+
+class Context:
+    """Owns one aur_ctx (one per device per thread)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        self.device = int(device)
+        h = C.c_void_p()
+        check(self.lib.aur_create(self.device, C.byref(h)), "aur_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.aur_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def window(self):
+        import numpy as np
+        w = np.empty(FFT_SIZE, dtype=np.float32)
+        check(self.lib.aur_get_window(self.handle, w.ctypes.data_as(C.c_void_p)), "aur_get_window")
+        return w

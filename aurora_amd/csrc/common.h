@@ -1,0 +1,57 @@
+// Internal declarations shared by the translation units of libaurora_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/aurora_hip.h"
+
+// Device-resident constant tables, computed in float64 on the host (abi.hip: build_tables).
+//   d_window : float32[2048]  periodic Hann w[n]                          audio/analysis.py:9
+//   d_twid   : float64, complex values stored as (re, im):
+//     [AUR_TW_W1 ..)  w1[l]     = W1024^l              l < 64   pass-1 twiddle base (powers are built per frame)
+//     [AUR_TW_WU ..)  wu[l]     = 0.5 * W2048^l        l < 64   real-FFT unpack twiddle base (0.5 folded in)
+//     [AUR_TW_W2 ..)  tw2[r][q] = W64^(r*q)            r < 4, q < 16   pass-2 twiddles
+//   with W_N = exp(-2 pi i / N).
+#define AUR_TW_W1      0
+#define AUR_TW_WU      128
+#define AUR_TW_W2      256
+#define AUR_TW_DOUBLES 384
+
+struct aur_ctx {
+    int device;
+    float* d_window;       // AUR_FFT_SIZE floats
+    double* d_twid;        // AUR_TW_DOUBLES doubles
+    float h_window[AUR_FFT_SIZE];
+    int num_cus;
+};
+
+void aur_set_error(const char* fmt, ...);
+
+#define AUR_CHECK_HIP(expr)                                                                 \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            aur_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return AUR_EHIP;                                                                \
+        }                                                                                   \
+    } while (0)
+
+#define AUR_REQUIRE(cond, ...)                                                              \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            aur_set_error(__VA_ARGS__);                                                     \
+            return AUR_EINVAL;                                                              \
+        }                                                                                   \
+    } while (0)
+
+// Sets the context's device current for the calling thread.
+static inline int aur_use_device(aur_ctx* ctx) {
+    if (!ctx) {
+        aur_set_error("null context");
+        return AUR_EINVAL;
+    }
+    AUR_CHECK_HIP(hipSetDevice(ctx->device));
+    return AUR_OK;
+}

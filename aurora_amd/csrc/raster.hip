@@ -1,0 +1,366 @@
+// Rasteriser for gfx950 (MI355X): per-frame column spans for the three linear export modes and the
+// tile-per-workgroup RGB24 fill that turns spans into the frames handed to FFmpeg.
+//
+// Replaces widgets/rt_widget.py:821-852 (paint_frame: fillRect + mode dispatch), :934-940/:982-988
+// (_draw_spectrum, linear), :903-913/:932 (_draw_waveform, linear), :990-1000 (_draw_particles) and the
+// QImage -> numpy copy of export/exporter.py:84-95.
+//
+// Coverage rule (documented in oracle/raster_ref.py; Qt's own raster engine is not part of the reference
+// tree, so pixel coverage is "parity unpinned" against Qt): a pixel is lit iff its centre lies inside the
+// outline of the width-2 SquareCap/BevelJoin stroke.  Every frame is described by column spans
+// (uint32 [F, K, W], r0 | r1 << 16 = lit rows [r0, r1) of a pixel column); the span kernels evaluate the
+// reference's arithmetic in its own precision chain (float32 normalise -> float64 geometry -> int truncation),
+// with contraction off, so they are bit-identical to the numpy oracle.  The fill kernel is pure HBM write
+// bandwidth: each lane owns 4 pixels of a row (12 B, one dwordx3 store, contiguous across the wave) and walks
+// the rows of its tile with its columns' spans held in registers.
+#include "common.h"
+
+namespace {
+
+constexpr double kBig = 1.0e6;
+
+__device__ __forceinline__ uint32_t pack_rows(long r0, long r1, int H) {
+    if (r0 < 0) r0 = 0;
+    if (r0 > H) r0 = H;
+    if (r1 < 0) r1 = 0;
+    if (r1 > H) r1 = H;
+    if (r1 <= r0) return 0u;
+    return (uint32_t)r0 | ((uint32_t)r1 << 16);
+}
+
+__device__ __forceinline__ float block_max_first(const float* row, int n, float* s_red) {
+    // max(row[:n]) for n <= 128 by the first 128 threads of the block, result broadcast through LDS
+    const int tid = threadIdx.x;
+    float v = (tid < n) ? row[tid] : -INFINITY;
+    if (tid < 128) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+        if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    }
+    __syncthreads();
+    return fmaxf(s_red[0], s_red[1]);
+}
+
+// ---- Spectrum - Linear: 80 bars (rt_widget.py:934-940, :982-988) ------------------------------------------
+__global__ __launch_bounds__(256) void spans_spectrum_kernel(const float* __restrict__ logspec,
+                                                             const double* __restrict__ energy, int W, int H,
+                                                             uint32_t* __restrict__ spans) {
+    __shared__ float s_red[2];
+    __shared__ int s_bh[AUR_N_BARS];
+    const int f = blockIdx.y;
+    const float* spec = logspec + (long)f * AUR_NBINS;
+    const float mxv = block_max_first(spec, AUR_N_BARS, s_red);
+    const float mx = (mxv > 0.0f) ? mxv : 1.0f;                 // rt_widget.py:939
+    const double scale = 0.4 + 0.6 * energy[f];                 // rt_widget.py:986
+    if (threadIdx.x < AUR_N_BARS) {
+        const float v32 = __fdiv_rn(spec[threadIdx.x], mx);    // spec / mx in float32 (rt_widget.py:940)
+        const double v = (double)v32;
+        s_bh[threadIdx.x] = (int)(v * (double)(H - 10) * scale);   // int(v * (h - 10) * (0.4 + 0.6 * energy))
+    }
+    __syncthreads();
+    const int bar_w = (W / AUR_N_BARS) > 1 ? (W / AUR_N_BARS) : 1;   // max(1, int(w / N)), rt_widget.py:983
+    uint32_t* out = spans + (long)f * AUR_K_SPECTRUM * W;
+    for (int px = blockIdx.x * 256 + threadIdx.x; px < W; px += gridDim.x * 256) {
+        uint32_t s0 = 0, s1 = 0;
+        // drawLine(x0, h-5, x0, h-5-bh), width 2: columns {x0-1, x0}, rows [h-6-bh, h-4)
+        if (px % bar_w == 0 && px / bar_w < AUR_N_BARS) {
+            const int bh = s_bh[px / bar_w];
+            const int ya = H - 5, yb = H - 5 - bh;
+            s0 = pack_rows((ya < yb ? ya : yb) - 1, (ya > yb ? ya : yb) + 1, H);
+        }
+        if ((px + 1) % bar_w == 0 && (px + 1) / bar_w < AUR_N_BARS) {
+            const int bh = s_bh[(px + 1) / bar_w];
+            const int ya = H - 5, yb = H - 5 - bh;
+            s1 = pack_rows((ya < yb ? ya : yb) - 1, (ya > yb ? ya : yb) + 1, H);
+        }
+        out[px] = s0;
+        out[W + px] = s1;
+    }
+}
+
+// ---- particles: 50 points (rt_widget.py:990-1000) ------------------------------------------------------------
+__global__ __launch_bounds__(256) void spans_particles_kernel(const float* __restrict__ logspec, int W, int H,
+                                                              uint32_t* __restrict__ spans) {
+    __shared__ float s_red[2];
+    __shared__ int s_x[AUR_N_PARTICLES], s_y[AUR_N_PARTICLES];
+    const int f = blockIdx.y;
+    const float* spec = logspec + (long)f * AUR_NBINS;
+    const float mxv = block_max_first(spec, AUR_N_PARTICLES, s_red);
+    const float den = mxv + 1e-6f;                              // np.max(spec) + 1e-6 stays float32 (NEP 50)
+    if (threadIdx.x < AUR_N_PARTICLES) {
+        const int i = threadIdx.x;
+        const double v = (double)__fdiv_rn(spec[i], den);
+        s_x[i] = (int)(((double)i + 0.5) / (double)AUR_N_PARTICLES * (double)W);
+        s_y[i] = (int)((double)H / 2.0 + (v - 0.5) * (double)H * 0.6);
+    }
+    __syncthreads();
+    uint32_t* out = spans + (long)f * AUR_K_PARTICLES * W;
+    for (int px = blockIdx.x * 256 + threadIdx.x; px < W; px += gridDim.x * 256) {
+        uint32_t s0 = 0, s1 = 0;
+        // drawPoint(x, y), width 2: the 2x2 block {x-1, x} x {y-1, y}; later points overwrite earlier ones
+        for (int i = 0; i < AUR_N_PARTICLES; ++i) {
+            if (s_x[i] == px) s0 = pack_rows(s_y[i] - 1, s_y[i] + 1, H);
+            if (s_x[i] - 1 == px) s1 = pack_rows(s_y[i] - 1, s_y[i] + 1, H);
+        }
+        out[px] = s0;
+        out[W + px] = s1;
+    }
+}
+
+// ---- Waveform - Linear: width-2 polyline (rt_widget.py:903-913, :932) ----------------------------------------
+
+__device__ __forceinline__ uint32_t rows_from_interval(double ylo, double yhi, bool valid, int H) {
+    if (!valid) return 0u;
+    ylo = fmin(fmax(ylo, -kBig), kBig);
+    yhi = fmin(fmax(yhi, -kBig), kBig);
+    const long r0 = (long)ceil(ylo - 0.5);
+    const long r1 = (long)floor(yhi - 0.5) + 1;
+    return pack_rows(r0, r1, H);
+}
+
+// y-interval of segment `seg`'s stroke rectangle (half-width 1, SquareCap at the path ends) on x = px + 0.5
+__device__ __forceinline__ uint32_t segment_rows(const double* Y, int seg, int px, int W, int H) {
+    const int nseg = W - 1;
+    if (seg < 0 || seg >= nseg) return 0u;
+    const double y0 = Y[seg], y1 = Y[seg + 1];
+    const double dy = y1 - y0;
+    const double L2 = 1.0 + dy * dy;
+    const double L = sqrt(L2);
+    const double rx = ((double)px + 0.5) - (double)seg;
+    const double c = rx * dy;
+    const double tlo = c - L, thi = c + L;
+    const double s0L = (seg == 0) ? -L : 0.0;
+    const double s1L = (seg == nseg - 1) ? L2 + L : L2;
+    double slo, shi;
+    bool ok = true;
+    if (dy > 0.0) {
+        slo = (s0L - rx) / dy;
+        shi = (s1L - rx) / dy;
+    } else if (dy < 0.0) {
+        slo = (s1L - rx) / dy;
+        shi = (s0L - rx) / dy;
+    } else {
+        slo = -kBig;
+        shi = kBig;
+        ok = (s0L <= rx) && (rx <= s1L);
+    }
+    const double lo = fmax(tlo, slo), hi = fmin(thi, shi);
+    return rows_from_interval(y0 + lo, y0 + hi, ok, H);
+}
+
+// y-interval of the BevelJoin triangle at interior vertex `v` on x = px + 0.5
+__device__ __forceinline__ uint32_t bevel_rows(const double* Y, int v, int px, int W, int H) {
+    if (v < 1 || v > W - 2) return 0u;
+    const double yv = Y[v];
+    const double dyA = yv - Y[v - 1];
+    const double dyB = Y[v + 1] - yv;
+    const double LA = sqrt(1.0 + dyA * dyA);
+    const double LB = sqrt(1.0 + dyB * dyB);
+    const double cr = dyB - dyA;
+    if (cr == 0.0) return 0u;
+    const double sg = (cr > 0.0) ? -1.0 : 1.0;
+    const double u1 = (sg * (-dyA)) / LA, w1 = sg / LA;
+    const double u2 = (sg * (-dyB)) / LB, w2 = sg / LB;
+    const double uc = ((double)px + 0.5) - (double)v;
+    double ymin = kBig, ymax = -kBig;
+    bool hit = false;
+    const double ua[3] = {0.0, 0.0, u1}, ya[3] = {0.0, 0.0, w1};
+    const double ub[3] = {u1, u2, u2}, yb[3] = {w1, w2, w2};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const double lo_u = fmin(ua[e], ub[e]), hi_u = fmax(ua[e], ub[e]);
+        if (ua[e] != ub[e] && lo_u <= uc && uc <= hi_u) {
+            const double yc = ya[e] + ((uc - ua[e]) * (yb[e] - ya[e])) / (ub[e] - ua[e]);
+            if (yc < ymin) ymin = yc;
+            if (yc > ymax) ymax = yc;
+            hit = true;
+        }
+    }
+    return rows_from_interval(yv + ymin, yv + ymax, hit, H);
+}
+
+constexpr int kWaveCols = 256;   // columns per block (one per thread); Y staged with a 2-column apron
+
+__global__ __launch_bounds__(256) void spans_waveform_kernel(const float* __restrict__ samples,
+                                                             const int* __restrict__ col2samp,
+                                                             const double* __restrict__ energy, int W, int H,
+                                                             uint32_t* __restrict__ spans) {
+    __shared__ double s_y[kWaveCols + 4];
+    const int f = blockIdx.y;
+    const float* smp = samples + (long)f * AUR_BLOCK;
+    const double e = energy[f];
+    const double amp = 0.45 * ((double)H / 2.0) * (0.5 + e);    // rt_widget.py:904
+    const float amp32 = (float)amp;                             // np.float32 * python float -> float32 (NEP 50)
+    const float mid32 = (float)((double)H / 2.0);               // rt_widget.py:905
+    const int x0 = blockIdx.x * kWaveCols;
+    for (int i = threadIdx.x; i < kWaveCols + 4; i += 256) {
+        const int x = x0 - 2 + i;
+        double y = 0.0;
+        if (x >= 0 && x < W) y = (double)(mid32 - smp[col2samp[x]] * amp32);   // rt_widget.py:908-909
+        s_y[i] = y;
+    }
+    __syncthreads();
+    const int px = x0 + threadIdx.x;
+    if (px >= W) return;
+    // s_y index of column x is x - x0 + 2; pass a pointer whose index is the absolute column
+    const double* Y = s_y + 2 - x0;
+    uint32_t* out = spans + (long)f * AUR_K_WAVEFORM * W;
+    uint32_t r[AUR_K_WAVEFORM] = {0u, 0u, 0u, 0u, 0u};
+    if (W >= 2) {
+        r[0] = segment_rows(Y, px - 1, px, W, H);
+        r[1] = segment_rows(Y, px, px, W, H);
+        r[2] = segment_rows(Y, px + 1, px, W, H);
+        r[3] = bevel_rows(Y, px, px, W, H);
+        r[4] = bevel_rows(Y, px + 1, px, W, H);
+    }
+#pragma unroll
+    for (int k = 0; k < AUR_K_WAVEFORM; ++k) out[(long)k * W + px] = r[k];
+}
+
+// ---- fill: spans -> RGB24 frames ----------------------------------------------------------------------------
+//
+// Block = 256 lanes = 1024 pixel columns x kRowsPerBlock rows of one frame.  A lane loads the spans of its 4
+// columns once (K x uint4), then for each row builds three dwords (4 RGB pixels) and stores them with one
+// 12-byte store; consecutive lanes store consecutive 12-byte groups, so a wave writes 768 contiguous bytes per
+// instruction.
+
+constexpr int kRowsPerBlock = 16;
+constexpr uint32_t kBg24 = 13u | (13u << 8) | (18u << 16);   // QColor(13, 13, 18), rt_widget.py:829
+
+struct __attribute__((packed, aligned(4))) rgb4 {
+    uint32_t d0, d1, d2;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void raster_fill_kernel(const uint32_t* __restrict__ spans,
+                                                          const uint32_t* __restrict__ pen_rgb, int W, int H,
+                                                          uint8_t* __restrict__ frames) {
+    const int f = blockIdx.z;
+    const int px0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (px0 >= W) return;
+    const int row0 = blockIdx.y * kRowsPerBlock;
+    const int row1 = (row0 + kRowsPerBlock < H) ? row0 + kRowsPerBlock : H;
+    const uint32_t pen = pen_rgb[f] & 0x00ffffffu;
+    const uint32_t* sp = spans + (long)f * K * W + px0;
+
+    uint32_t lo[K][4], len[K][4];
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint4 s = *reinterpret_cast<const uint4*>(sp + (long)k * W);
+        const uint32_t v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            lo[k][c] = v[c] & 0xffffu;
+            len[k][c] = (v[c] >> 16) - (v[c] & 0xffffu);   // 0 for an empty span
+            any |= v[c];
+        }
+    }
+    uint8_t* base = frames + ((long)f * H + row0) * (long)W * 3 + (long)px0 * 3;
+    const rgb4 bgv = {kBg24 | (kBg24 << 24), (kBg24 >> 8) | (kBg24 << 16), (kBg24 >> 16) | (kBg24 << 8)};
+    if (any == 0) {
+        for (int row = row0; row < row1; ++row) {
+            *reinterpret_cast<rgb4*>(base) = bgv;
+            base += (long)W * 3;
+        }
+        return;
+    }
+    for (int row = row0; row < row1; ++row) {
+        uint32_t col[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bool lit = false;
+#pragma unroll
+            for (int k = 0; k < K; ++k) lit |= ((uint32_t)row - lo[k][c]) < len[k][c];
+            col[c] = lit ? pen : kBg24;
+        }
+        rgb4 o;
+        o.d0 = col[0] | (col[1] << 24);
+        o.d1 = (col[1] >> 8) | (col[2] << 16);
+        o.d2 = (col[2] >> 16) | (col[3] << 8);
+        *reinterpret_cast<rgb4*>(base) = o;
+        base += (long)W * 3;
+    }
+}
+
+int check_raster_dims(const char* who, int n_frames, int W, int H) {
+    AUR_REQUIRE(n_frames >= 0, "%s: n_frames %d < 0", who, n_frames);
+    AUR_REQUIRE(W >= 160 && W <= 16384 && H >= 16 && H <= 16384, "%s: frame size %dx%d outside [160..16384]x[16..16384]",
+                who, W, H);
+    AUR_REQUIRE(n_frames <= 65535, "%s: n_frames %d > 65535 per call", who, n_frames);
+    return AUR_OK;
+}
+
+}  // namespace
+
+extern "C" int aur_spans_spectrum_linear(aur_ctx* ctx, const float* d_logspec, const double* d_energy, int n_frames,
+                                         int W, int H, uint32_t* d_spans, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_raster_dims("aur_spans_spectrum_linear", n_frames, W, H))) return rc;
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_logspec && d_energy && d_spans, "aur_spans_spectrum_linear: null device pointer");
+    const unsigned gx = (unsigned)((W + 255) / 256);
+    hipLaunchKernelGGL(spans_spectrum_kernel, dim3(gx, n_frames), dim3(256), 0, (hipStream_t)stream, d_logspec,
+                       d_energy, W, H, d_spans);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_spans_particles(aur_ctx* ctx, const float* d_logspec, int n_frames, int W, int H,
+                                   uint32_t* d_spans, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_raster_dims("aur_spans_particles", n_frames, W, H))) return rc;
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_logspec && d_spans, "aur_spans_particles: null device pointer");
+    const unsigned gx = (unsigned)((W + 255) / 256);
+    hipLaunchKernelGGL(spans_particles_kernel, dim3(gx, n_frames), dim3(256), 0, (hipStream_t)stream, d_logspec, W,
+                       H, d_spans);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_spans_waveform_linear(aur_ctx* ctx, const float* d_samples, const int32_t* d_col2samp,
+                                         const double* d_energy, int n_frames, int W, int H, uint32_t* d_spans,
+                                         void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_raster_dims("aur_spans_waveform_linear", n_frames, W, H))) return rc;
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_samples && d_col2samp && d_energy && d_spans, "aur_spans_waveform_linear: null device pointer");
+    const unsigned gx = (unsigned)((W + kWaveCols - 1) / kWaveCols);
+    hipLaunchKernelGGL(spans_waveform_kernel, dim3(gx, n_frames), dim3(256), 0, (hipStream_t)stream, d_samples,
+                       d_col2samp, d_energy, W, H, d_spans);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_raster_spans(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb, int n_frames,
+                                int W, int H, uint8_t* d_frames, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_raster_dims("aur_raster_spans", n_frames, W, H))) return rc;
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_spans && d_pen_rgb && d_frames, "aur_raster_spans: null device pointer");
+    AUR_REQUIRE(W % 4 == 0, "aur_raster_spans: width %d must be a multiple of 4", W);
+    AUR_REQUIRE(((uintptr_t)d_frames & 3u) == 0 && ((uintptr_t)d_spans & 15u) == 0 && ((uintptr_t)d_pen_rgb & 3u) == 0,
+                "aur_raster_spans: misaligned device pointer");
+    const dim3 grid((unsigned)((W / 4 + 255) / 256), (unsigned)((H + kRowsPerBlock - 1) / kRowsPerBlock),
+                    (unsigned)n_frames);
+    const uint32_t* pen = reinterpret_cast<const uint32_t*>(d_pen_rgb);
+    hipStream_t st = (hipStream_t)stream;
+    switch (K) {
+        case 2:
+            hipLaunchKernelGGL(raster_fill_kernel<2>, grid, dim3(256), 0, st, d_spans, pen, W, H, d_frames);
+            break;
+        case 5:
+            hipLaunchKernelGGL(raster_fill_kernel<5>, grid, dim3(256), 0, st, d_spans, pen, W, H, d_frames);
+            break;
+        default:
+            aur_set_error("aur_raster_spans: K=%d unsupported (2 or 5)", K);
+            return AUR_EINVAL;
+    }
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}

@@ -1,0 +1,519 @@
+// Fused per-frame analysis kernel for gfx950 (MI355X): gather -> mono mix -> zero-pad -> Hann ->
+// 2048-point real FFT -> |X| -> log1p / spectral-flux partial / mean|x| / band maxima.
+//
+// Replaces export/exporter.py:227-238 (_read_frame) + audio/analysis.py:16-33 (Analyzer.compute) +
+// the energy of widgets/rt_widget.py:824 for a whole range of frames per launch.
+//
+// Arithmetic: the reference's np.fft.rfft(float32) resolves to numpy's float64 pocketfft loop ('dd->D' is the
+// first matching loop of the ufunc) and the result is rounded to complex64, so the reference spectrum is a
+// float64 FFT of the float32 product buffer*window.  Leakage bins sit 8-9 decades below the peak of a frame,
+// which a float32 butterfly network cannot resolve (its rounding error is relative to the peak).  The FFT here
+// therefore runs in float64 -- the MI355X vector ALU executes v_fma_f64 at half the float32 rate -- and only the
+// window product (as in the reference), |X| -> log1p and the flux run in float32.
+//
+// Design (one 64-lane wavefront per frame, frames_per_wave consecutive frames per wave):
+//  * the 2048-point real FFT is a 1024-point complex FFT of z[n] = x[2n] + i x[2n+1] plus an unpack pass;
+//  * 1024 = 16 x 16 x 4: lane l holds z[l + 64 j] (16 complex values in registers).  Pass 1 is a radix-16
+//    DFT in registers, pass 2 a radix-16 DFT after an LDS transpose, pass 3 a radix-4 after a second LDS
+//    transpose.  The index split is chosen so pass 3 leaves Z[l + 64 j] in lane l again, which is the
+//    coalesced store order of the spectrum (bins l + 64 j) -- no third transpose;
+//  * the transposes move real and imaginary parts separately (ds_write_b64 / ds_read_b64, rows padded to 66
+//    doubles: conflict-free both ways), so a wave needs 8.25 KB of LDS and 12 waves fit a CU next to the tables;
+//  * the unpack partner Z[1024-k] lives in lane (64 - l) % 64 and is fetched with ds_bpermute (no LDS memory);
+//  * lane-dependent twiddles W1024^(l k1) and W2048^(l + 64 j) are powers / constant multiples of one per-lane
+//    base value held in registers; the small W64^(r q) table and the window are staged in LDS once per workgroup;
+//  * a wave walks consecutive frames, so the previous 1024-sample block (Analyzer.buffer[:1024]) and the
+//    previous magnitudes (Analyzer.prev_mag) stay in registers; HBM sees every audio sample once per chunk
+//    (plus a 2-block halo per chunk) and every output once;
+//  * mean|x| is summed in numpy's pairwise order so the energy is bit-identical to the reference.
+//
+// Contraction is disabled for the whole library (-ffp-contract=off); fma is used explicitly where wanted.
+#include "common.h"
+
+namespace {
+
+constexpr int kWavesPerWG = 4;
+constexpr int kXbufDoubles = 16 * 66;            // exchange buffer per wave: 16 rows of 66 doubles, 8448 B
+constexpr int kLdsWinBytes = AUR_FFT_SIZE * 4;   // float32 window
+constexpr int kLdsTw2Bytes = 4 * 16 * 16;        // W64^(r q), complex double
+constexpr int kLdsBytes = kLdsWinBytes + kLdsTw2Bytes + kWavesPerWG * kXbufDoubles * 8;
+
+struct cd {
+    double x, y;
+};
+
+__device__ __forceinline__ cd cadd(cd a, cd b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cd csub(cd a, cd b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cd cmul(cd a, cd w) {
+    return {fma(a.x, w.x, -(a.y * w.y)), fma(a.x, w.y, a.y * w.x)};
+}
+__device__ __forceinline__ cd mul_mi(cd a) { return {a.y, -a.x}; }   // * (-i)
+
+// Orders LDS traffic between the lanes of ONE wave (lanes run in lockstep; this only stops the compiler
+// from moving LDS accesses across the exchange point).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Returns its argument through an empty asm so the compiler treats it as a new value: keeps per-frame twiddle
+// arithmetic inside the frame loop instead of hoisting 30 complex doubles into registers.
+__device__ __forceinline__ cd opaque(cd w) {
+    asm volatile("" : "+v"(w.x), "+v"(w.y));
+    return w;
+}
+
+// forward radix-4 butterfly, outputs in natural order
+__device__ __forceinline__ void radix4(cd& x0, cd& x1, cd& x2, cd& x3) {
+    const cd t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = mul_mi(csub(x1, x3));
+    x0 = cadd(t0, t2);
+    x1 = cadd(t1, t3);
+    x2 = csub(t0, t2);
+    x3 = csub(t1, t3);
+}
+
+// In-register 16-point forward DFT.  Input v[j], j = 4a + b.  Output X[k], k = c + 4d, is left in v[4c + d].
+__device__ __forceinline__ void dft16(cd (&v)[16]) {
+    constexpr double C1 = 0.92387953251128673848;   // cos(pi/8)
+    constexpr double S1 = 0.38268343236508978178;   // sin(pi/8)
+    constexpr double H = 0.70710678118654752440;    // sqrt(1/2)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) radix4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    // now v[4c + b] = T[b][c]; multiply by W16^(b c)
+    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], cd{C1, -S1});                                  // W^1
+    v[4 * 2 + 1] = cd{H * (v[4 * 2 + 1].x + v[4 * 2 + 1].y), H * (v[4 * 2 + 1].y - v[4 * 2 + 1].x)};   // W^2
+    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], cd{S1, -C1});                                  // W^3
+    v[4 * 1 + 2] = cd{H * (v[4 * 1 + 2].x + v[4 * 1 + 2].y), H * (v[4 * 1 + 2].y - v[4 * 1 + 2].x)};   // W^2
+    v[4 * 2 + 2] = mul_mi(v[4 * 2 + 2]);                                             // W^4 = -i
+    v[4 * 3 + 2] = cd{H * (v[4 * 3 + 2].y - v[4 * 3 + 2].x), -H * (v[4 * 3 + 2].x + v[4 * 3 + 2].y)};  // W^6
+    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], cd{S1, -C1});                                  // W^3
+    v[4 * 2 + 3] = cd{H * (v[4 * 2 + 3].y - v[4 * 2 + 3].x), -H * (v[4 * 2 + 3].x + v[4 * 2 + 3].y)};  // W^6
+    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], cd{-C1, S1});                                  // W^9
+#pragma unroll
+    for (int c = 0; c < 4; ++c) radix4(v[4 * c + 0], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+}
+
+// p[k] = w^k for k = 1..15 by a depth-4 product tree (p[0] is not used)
+__device__ __forceinline__ void pow_chain(cd w, cd (&p)[16]) {
+    p[0] = cd{1.0, 0.0};
+    p[1] = w;
+    p[2] = cmul(p[1], p[1]);
+    p[3] = cmul(p[2], p[1]);
+    p[4] = cmul(p[2], p[2]);
+    p[5] = cmul(p[4], p[1]);
+    p[6] = cmul(p[3], p[3]);
+    p[7] = cmul(p[4], p[3]);
+    p[8] = cmul(p[4], p[4]);
+    p[9] = cmul(p[8], p[1]);
+    p[10] = cmul(p[5], p[5]);
+    p[11] = cmul(p[8], p[3]);
+    p[12] = cmul(p[6], p[6]);
+    p[13] = cmul(p[8], p[5]);
+    p[14] = cmul(p[7], p[7]);
+    p[15] = cmul(p[8], p[7]);
+}
+
+__device__ __forceinline__ float wave_sum_xor(float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max_xor(float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+__device__ __forceinline__ double bperm_f64(int src_lane4, double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane4, (int)(b & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane4, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+
+// One 1024-sample analysis block of frame `fi` (exporter.py:230-237) in the lane layout of the FFT:
+// blk[2jj], blk[2jj+1] = samples[2*lane + 128*jj], samples[2*lane + 128*jj + 1].
+template <int C>
+__device__ __forceinline__ void load_block(const float* __restrict__ audio, long n_samp,
+                                           const long* __restrict__ pos, long fi, int hop, int lane,
+                                           float (&blk)[16]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) blk[i] = 0.0f;
+    if (fi < 0) return;
+    const long p = pos[fi];
+    long nv = n_samp - p;
+    if (nv > hop) nv = hop;
+    if (nv > AUR_BLOCK) nv = AUR_BLOCK;
+    const int nvalid = (int)nv;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int s = 2 * lane + 128 * jj;
+        if (C == 2) {
+            const float2* src = reinterpret_cast<const float2*>(audio + (p + s) * 2);
+            if (s + 1 < nvalid) {
+                const float2 a = src[0], b = src[1];
+                blk[2 * jj] = (a.x + a.y) * 0.5f;        // y.mean(axis=1), exporter.py:234
+                blk[2 * jj + 1] = (b.x + b.y) * 0.5f;
+            } else if (s < nvalid) {
+                const float2 a = src[0];
+                blk[2 * jj] = (a.x + a.y) * 0.5f;
+            }
+        } else {
+            const float* src = audio + (p + s);
+            if (s < nvalid) blk[2 * jj] = src[0];
+            if (s + 1 < nvalid) blk[2 * jj + 1] = src[1];
+        }
+    }
+}
+
+struct Tables {
+    const float2* win;   // LDS: (w[2n], w[2n+1]), n < 1024
+    const cd* tw2;       // LDS: W64^(r q), [r][q]
+    cd w1;               // W1024^lane
+    cd wuh;              // 0.5 * W2048^lane
+};
+
+// Stages the window and the W64 table into LDS (whole workgroup), loads the per-lane twiddle bases.  Ends with
+// a barrier.
+__device__ __forceinline__ Tables stage_tables(const float* __restrict__ window, const double* __restrict__ twid,
+                                               unsigned char* smem, int lane) {
+    float4* w4 = reinterpret_cast<float4*>(smem);
+    const float4* wsrc = reinterpret_cast<const float4*>(window);
+    for (int i = threadIdx.x; i < AUR_FFT_SIZE / 4; i += blockDim.x) w4[i] = wsrc[i];
+    double* t2 = reinterpret_cast<double*>(smem + kLdsWinBytes);
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) t2[i] = twid[AUR_TW_W2 + i];
+    Tables t;
+    t.win = reinterpret_cast<const float2*>(smem);
+    t.tw2 = reinterpret_cast<const cd*>(t2);
+    t.w1 = cd{twid[AUR_TW_W1 + 2 * lane], twid[AUR_TW_W1 + 2 * lane + 1]};
+    t.wuh = cd{twid[AUR_TW_WU + 2 * lane], twid[AUR_TW_WU + 2 * lane + 1]};
+    __syncthreads();
+    return t;
+}
+
+// mean(|samples|) of one block in numpy's pairwise order (8 blocks of 128, 8 strided accumulators each, then
+// the fixed add tree); `xf` is the wave's exchange buffer.  Returns the mean in every lane.
+__device__ __forceinline__ float block_meanabs(const float (&cur)[16], int lane, float* xf) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        float2 a = {fabsf(cur[2 * jj]), fabsf(cur[2 * jj + 1])};
+        *reinterpret_cast<float2*>(xf + 2 * lane + 136 * jj) = a;   // element i lives at i + 8 * (i / 128)
+    }
+    wave_sync();
+    const float* e = xf + 136 * (lane >> 3) + (lane & 7);
+    float r = e[0];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) r += e[8 * t];
+    r = wave_sum_xor(r);
+    wave_sync();
+    return r * (1.0f / 1024.0f);
+}
+
+// 1024-point complex FFT (float64) of the windowed, packed 2048-sample buffer [prv | cur].
+// In: prv/cur[2jj], [2jj+1] = block samples 2*lane + 128*jj, +1.
+// Out: Z[lane + 64 j] is left in v[4 * (j & 3) + (j >> 2)]  (see zreg()).
+__device__ __forceinline__ void fft_packed(const float (&prv)[16], const float (&cur)[16], int lane,
+                                           const Tables& T, double* xb, cd (&v)[16]) {
+    // window in float32 exactly as the reference (buffer * window, analysis.py:25), then widen and pack:
+    // z[l + 64 j] = (x[2n] w[2n], x[2n+1] w[2n+1])
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float2 w = T.win[lane + 64 * j];
+        v[j] = cd{(double)(prv[2 * j] * w.x), (double)(prv[2 * j + 1] * w.y)};
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float2 w = T.win[lane + 64 * (j + 8)];
+        v[j + 8] = cd{(double)(cur[2 * j] * w.x), (double)(cur[2 * j + 1] * w.y)};
+    }
+    // pass 1: radix-16 over j, twiddle W1024^(l k1), transpose through LDS (rows padded to 66: conflict-free)
+    dft16(v);
+    {
+        // the powers are rebuilt per frame on purpose: kept across frames they would pin 60 VGPRs (opaque())
+        cd p[16];
+        pow_chain(opaque(T.w1), p);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) {
+            const int k1 = (i >> 2) + 4 * (i & 3);
+            v[i] = cmul(v[i], p[k1]);
+        }
+    }
+    const int lo4 = lane & 15, hi2 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xb[lane + 66 * ((i >> 2) + 4 * (i & 3))] = v[i].x;
+    wave_sync();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) v[p].x = xb[(hi2 + 4 * p) + 66 * lo4];
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xb[lane + 66 * ((i >> 2) + 4 * (i & 3))] = v[i].y;
+    wave_sync();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) v[p].y = xb[(hi2 + 4 * p) + 66 * lo4];
+    wave_sync();
+    // pass 2: radix-16 over p (lane = k1 + 16 r), twiddle W64^(r q), transpose through LDS
+    dft16(v);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+        const int q = (i >> 2) + 4 * (i & 3);
+        v[i] = cmul(v[i], T.tw2[hi2 * 16 + q]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xb[lo4 + 16 * ((i >> 2) + 4 * (i & 3)) + 256 * hi2] = v[i].x;
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i].x = xb[lane + 64 * (i >> 2) + 256 * (i & 3)];   // i = 4 ql + r
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xb[lo4 + 16 * ((i >> 2) + 4 * (i & 3)) + 256 * hi2] = v[i].y;
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i].y = xb[lane + 64 * (i >> 2) + 256 * (i & 3)];
+    wave_sync();
+    // pass 3: radix-4 over r (lane = k1 + 16 qh holds q = qh + 4 ql); v[4 ql + s] = Z[lane + 64 (ql + 4 s)]
+#pragma unroll
+    for (int ql = 0; ql < 4; ++ql) radix4(v[4 * ql + 0], v[4 * ql + 1], v[4 * ql + 2], v[4 * ql + 3]);
+}
+
+// register of v[] that holds Z[lane + 64 j] after fft_packed
+__device__ __forceinline__ constexpr int zreg(int j) { return 4 * (j & 3) + (j >> 2); }
+
+// |X| in float32 from |X|^2 in float64: one rounding into float32, v_sqrt_f32 (1 ulp); the rare values whose
+// square leaves the float32 normal range take the float64 square root.
+__device__ __forceinline__ float mag_from_sq(double m2) {
+    const float f = (float)m2;
+    float mag = __builtin_amdgcn_sqrtf(f);
+    if (__builtin_expect((f < 1.0e-30f && m2 > 0.0) || f > 1.0e30f, 0)) mag = (float)sqrt(m2);
+    return mag;
+}
+
+// W32^j = exp(-2 pi i j / 32), j < 16
+__device__ constexpr double kW32re[16] = {
+    1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+    0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785,
+    0.0, -0.19509032201612826785, -0.38268343236508977173, -0.55557023301960222474,
+    -0.70710678118654752440, -0.83146961230254523708, -0.92387953251128675613, -0.98078528040323044913};
+__device__ constexpr double kW32im[16] = {
+    -0.0, -0.19509032201612826785, -0.38268343236508977173, -0.55557023301960222474,
+    -0.70710678118654752440, -0.83146961230254523708, -0.92387953251128675613, -0.98078528040323044913,
+    -1.0, -0.98078528040323044913, -0.92387953251128675613, -0.83146961230254523708,
+    -0.70710678118654752440, -0.55557023301960222474, -0.38268343236508977173, -0.19509032201612826785};
+
+// Real-FFT unpack -> |X| -> flux partial vs pmag (updated in place) -> log1p.
+// Bins k = lane + 64 j; the partner Z[1024 - k] sits in lane (64 - lane) % 64 and is fetched with ds_bpermute.
+// lg[j] = log1p|X[lane + 64 j]|, lg_ny = log1p|X[1024]| (valid in lane 0).  Returns this lane's flux partial.
+__device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, bool emit,
+                                            float (&pmag)[16], float& pmag_ny, float (&lg)[16], float& lg_ny) {
+    const int src_lane4 = ((64 - lane) & 63) * 4;
+    const cd wuh = opaque(T.wuh);
+    float fl = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double c = bperm_f64(src_lane4, v[zreg(15 - j)].x);
+        double d = bperm_f64(src_lane4, v[zreg(15 - j)].y);
+        if (lane == 0) {   // lane 0: partner of bin 64 j is bin 1024 - 64 j = own register 16 - j (bin 0: itself)
+            const cd own = (j == 0) ? v[zreg(0)] : v[zreg(16 - j)];
+            c = own.x;
+            d = own.y;
+        }
+        const double a = v[zreg(j)].x, b = v[zreg(j)].y;
+        // th = 0.5 * W2048^(lane + 64 j) = wuh * W32^j
+        const cd th = (j == 0) ? wuh : cmul(wuh, cd{kW32re[j], kW32im[j]});
+        const double ex = a + c, ey = b - d;     // 2E = Z[k] + conj(Z[N-k])
+        const double ox = b + d, oy = c - a;     // 2O = -i (Z[k] - conj(Z[N-k]))
+        const double re = fma(0.5, ex, fma(th.x, ox, -(th.y * oy)));
+        const double im = fma(0.5, ey, fma(th.x, oy, th.y * ox));
+        const float mag = mag_from_sq(fma(re, re, im * im));
+        fl += fmaxf(0.0f, mag - pmag[j]);
+        pmag[j] = mag;
+        if (emit) lg[j] = log1pf(mag);
+    }
+    {   // bin 1024 = Re Z[0] - Im Z[0] (lane 0)
+        const float mag = (float)fabs(v[zreg(0)].x - v[zreg(0)].y);
+        if (lane == 0) {
+            fl += fmaxf(0.0f, mag - pmag_ny);
+            pmag_ny = mag;
+        }
+        if (emit) lg_ny = log1pf(mag);
+    }
+    return fl;
+}
+
+template <int C>
+__global__ __launch_bounds__(kWavesPerWG * 64, 2) void stft_frames_kernel(
+    const float* __restrict__ audio, long n_samp, const long* __restrict__ pos, long frame_begin, int n_frames,
+    int hop, int frames_per_wave, const float* __restrict__ window, const double* __restrict__ twid,
+    float* __restrict__ logspec, float* __restrict__ flux_sum, float* __restrict__ meanabs,
+    float* __restrict__ samples_out, float* __restrict__ bandmax) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const Tables T = stage_tables(window, twid, smem, lane);
+
+    double* xb = reinterpret_cast<double*>(smem + kLdsWinBytes + kLdsTw2Bytes) + wave * kXbufDoubles;   // wave-private
+    float* xf = reinterpret_cast<float*>(xb);
+
+    const long gw = (long)blockIdx.x * kWavesPerWG + wave;
+    const long frame_end = frame_begin + n_frames;
+    const long c0 = frame_begin + gw * frames_per_wave;
+    if (c0 >= frame_end) return;   // no block-level barrier below this point
+    const long cend = (c0 + frames_per_wave < frame_end) ? c0 + frames_per_wave : frame_end;
+
+    float prv[16], cur[16], pmag[16], lg[16];
+    float pmag_ny = 0.0f, lg_ny = 0.0f;   // bin 1024 (lane 0 only)
+    cd v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        pmag[i] = 0.0f;
+        lg[i] = 0.0f;
+    }
+    const bool want_log = (logspec != nullptr) || (bandmax != nullptr);
+
+    // Analyzer.buffer starts at zero (analysis.py:14); a chunk that starts inside the track first replays frame
+    // c0 - 1 (the halo) to rebuild Analyzer.prev_mag, storing nothing.
+    const long fstart = (c0 > 0) ? c0 - 1 : c0;
+    load_block<C>(audio, n_samp, pos, fstart - 1, hop, lane, prv);
+
+    for (long f = fstart; f < cend; ++f) {
+        load_block<C>(audio, n_samp, pos, f, hop, lane, cur);
+        const bool store = f >= c0;            // wave-uniform
+        const long fo = f - frame_begin;
+
+        if (store) {
+            const float ma = block_meanabs(cur, lane, xf);
+            if (lane == 0) meanabs[fo] = ma;
+            if (samples_out != nullptr) {
+                float* dst = samples_out + fo * AUR_BLOCK;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    *reinterpret_cast<float2*>(dst + 2 * lane + 128 * jj) = float2{cur[2 * jj], cur[2 * jj + 1]};
+            }
+        }
+
+        fft_packed(prv, cur, lane, T, xb, v);
+        // analysis-only pre-pass (carried smoothing state) and the halo frame: no log1p, no spectrum store
+        float fl = unpack_mag(v, lane, T, want_log && store, pmag, pmag_ny, lg, lg_ny);
+        if (store) {
+            if (logspec != nullptr) {
+                float* out = logspec + fo * AUR_NBINS;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) out[lane + 64 * j] = lg[j];
+                if (lane == 0) out[1024] = lg_ny;
+            }
+            fl = wave_sum_xor(fl);
+            if (lane == 0) flux_sum[fo] = fl;
+            if (bandmax != nullptr) {
+                // bins < 80: j = 0 (all lanes) and j = 1 (lanes < 16); bins < 50: j = 0, lanes < 50.  log1p >= 0.
+                float bm80 = fmaxf(lg[0], (lane < 16) ? lg[1] : 0.0f);
+                float bm50 = (lane < 50) ? lg[0] : 0.0f;
+                bm80 = wave_max_xor(bm80);
+                bm50 = wave_max_xor(bm50);
+                if (lane == 0) {
+                    bandmax[2 * fo] = bm80;
+                    bandmax[2 * fo + 1] = bm50;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prv[i] = cur[i];
+    }
+}
+
+// One Analyzer.compute step (audio/analysis.py:25-33) on an already-slid 2048-sample buffer: one wave.
+__global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict__ buffer,
+                                                         float* __restrict__ prev_mag,
+                                                         const float* __restrict__ window,
+                                                         const double* __restrict__ twid,
+                                                         float* __restrict__ logspec,
+                                                         float* __restrict__ flux_sum) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsWinBytes + kLdsTw2Bytes + kXbufDoubles * 8];
+    const int lane = threadIdx.x;
+    const Tables T = stage_tables(window, twid, smem, lane);
+    double* xb = reinterpret_cast<double*>(smem + kLdsWinBytes + kLdsTw2Bytes);
+    float prv[16], cur[16], pmag[16], lg[16];
+    float pmag_ny = 0.0f, lg_ny = 0.0f;
+    cd v[16];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const float2 a = *reinterpret_cast<const float2*>(buffer + 2 * lane + 128 * jj);
+        const float2 b = *reinterpret_cast<const float2*>(buffer + AUR_BLOCK + 2 * lane + 128 * jj);
+        prv[2 * jj] = a.x;
+        prv[2 * jj + 1] = a.y;
+        cur[2 * jj] = b.x;
+        cur[2 * jj + 1] = b.y;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pmag[j] = prev_mag[lane + 64 * j];
+    if (lane == 0) pmag_ny = prev_mag[1024];
+    fft_packed(prv, cur, lane, T, xb, v);
+    float fl = unpack_mag(v, lane, T, true, pmag, pmag_ny, lg, lg_ny);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        logspec[lane + 64 * j] = lg[j];
+        prev_mag[lane + 64 * j] = pmag[j];
+    }
+    if (lane == 0) {
+        logspec[1024] = lg_ny;
+        prev_mag[1024] = pmag_ny;
+    }
+    fl = wave_sum_xor(fl);
+    if (lane == 0) flux_sum[0] = fl;
+}
+
+template <int C>
+int launch_stft(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int64_t* d_pos, int64_t frame_begin,
+                int n_frames, int hop, float* d_logspec, float* d_flux_sum, float* d_meanabs, float* d_samples,
+                float* d_bandmax, hipStream_t st) {
+    // frames per wave: long enough to amortise the 1-frame halo, short enough to fill 256 CUs
+    int fpw = 32;
+    const long waves_wanted = (long)ctx->num_cus * 12 * 2;
+    while (fpw > 4 && (long)(n_frames + fpw - 1) / fpw < waves_wanted) fpw >>= 1;
+    const long n_waves = ((long)n_frames + fpw - 1) / fpw;
+    const unsigned grid = (unsigned)((n_waves + kWavesPerWG - 1) / kWavesPerWG);
+    hipLaunchKernelGGL(stft_frames_kernel<C>, dim3(grid), dim3(kWavesPerWG * 64), kLdsBytes, st, d_audio,
+                       (long)n_samples, (const long*)d_pos, (long)frame_begin, n_frames, hop, fpw, ctx->d_window,
+                       ctx->d_twid, d_logspec, d_flux_sum, d_meanabs, d_samples, d_bandmax);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+}  // namespace
+
+extern "C" int aur_stft_frames(aur_ctx* ctx, const float* d_audio, int64_t n_samples, int channels,
+                               const int64_t* d_pos, int64_t frame_begin, int n_frames, int hop, float* d_logspec,
+                               float* d_flux_sum, float* d_meanabs, float* d_samples, float* d_bandmax,
+                               void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0, "aur_stft_frames: n_frames %d < 0", n_frames);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_audio && d_pos && d_flux_sum && d_meanabs, "aur_stft_frames: null device pointer");
+    AUR_REQUIRE(n_samples > 0, "aur_stft_frames: n_samples %lld <= 0", (long long)n_samples);
+    AUR_REQUIRE(channels == 1 || channels == 2, "aur_stft_frames: channels %d unsupported (1 or 2)", channels);
+    AUR_REQUIRE(hop >= 1, "aur_stft_frames: hop %d < 1", hop);
+    AUR_REQUIRE(frame_begin >= 0, "aur_stft_frames: frame_begin %lld < 0", (long long)frame_begin);
+    AUR_REQUIRE(((uintptr_t)d_audio & 7u) == 0 &&
+                    (d_samples == nullptr || ((uintptr_t)d_samples & 7u) == 0),
+                "aur_stft_frames: misaligned device pointer");
+    static_assert(kLdsBytes <= 48 * 1024, "dynamic LDS above 48 KB needs hipFuncSetAttribute");
+    hipStream_t st = (hipStream_t)stream;
+    if (channels == 2)
+        return launch_stft<2>(ctx, d_audio, n_samples, d_pos, frame_begin, n_frames, hop, d_logspec, d_flux_sum,
+                              d_meanabs, d_samples, d_bandmax, st);
+    return launch_stft<1>(ctx, d_audio, n_samples, d_pos, frame_begin, n_frames, hop, d_logspec, d_flux_sum,
+                          d_meanabs, d_samples, d_bandmax, st);
+}
+
+extern "C" int aur_stft_buffer(aur_ctx* ctx, const float* d_buffer, float* d_prev_mag, float* d_logspec,
+                               float* d_flux_sum, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(d_buffer && d_prev_mag && d_logspec && d_flux_sum, "aur_stft_buffer: null device pointer");
+    AUR_REQUIRE(((uintptr_t)d_buffer & 7u) == 0, "aur_stft_buffer: d_buffer must be 8-byte aligned");
+    hipLaunchKernelGGL(stft_buffer_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_buffer, d_prev_mag,
+                       ctx->d_window, ctx->d_twid, d_logspec, d_flux_sum);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}

@@ -1,0 +1,401 @@
+"""Drop-in for the reference's ``export/exporter.py`` on MI355X.
+
+Keeps the surface the UI and ``export.worker`` use (export/exporter.py):
+
+* ``Exporter(audio_path, width, height, fps, mode, color, sensitivity, prefer_hevc, view_state,
+  gpu_rendering, gpu_device)`` with ``render_to_file(out_path, progress_cb)`` and
+  ``_run_pipe(renderer, cmd, progress_cb)``  (:494-567);
+* a renderer with the duck type ``.duration`` + ``.render_time(t) -> uint8[h, w, 3]``  (:98-252);
+* ``build_ffmpeg_cmd(...) -> (argv, "rgb24")`` and ``list_gpu_export_devices()``  (:368-491).
+
+The frame source is ``HipOffscreenRenderer``: the track is uploaded to HBM once, analysed in one fused
+launch, rasterised in batches and read back through a pinned ring (``aurora_amd.pipeline``).  PySide6 and
+soundfile are optional; there is no CPU rendering fallback.
+
+``gpu_device`` keeps its reference meaning (an FFmpeg *encoder* id).  The compute device is selected with the
+new key ``hip_device`` (int) in ``view_state``; time sharding with ``hip_frame_range`` = [begin, end).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import platform
+import shutil
+import subprocess
+import wave
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from ..engine import get_engine, mode_kind, SUPPORTED_KINDS
+from ..pipeline import FramePipeline
+
+logger = logging.getLogger(__name__)
+
+
+# ----------------------------------------------------------------------------- audio ingest
+
+def _read_wav_stdlib(path):
+    """PCM WAV -> (float32 [n, C] in [-1, 1), samplerate) using the stdlib (soundfile-free fallback)."""
+    with wave.open(path, "rb") as w:
+        ch, sw, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(n)
+    if sw == 2:
+        a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif sw == 4:
+        a = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif sw == 1:
+        a = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif sw == 3:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v & 0x800000, v - 0x1000000, v)
+        a = v.astype(np.float32) / 8388608.0
+    else:
+        raise RuntimeError(f"unsupported WAV sample width {sw}")
+    return a.reshape(-1, ch), sr
+
+
+def load_audio(path):
+    """Whole file as float32 [n, C] + samplerate: soundfile if installed (exporter.py:110), else float/PCM WAV
+    through scipy/stdlib, else FFmpeg decode to mono 48 kHz (the reference's _FFmpegDecodedAudio, :46-81)."""
+    try:
+        import soundfile as sf
+        data, sr = sf.read(path, dtype="float32", always_2d=True)
+        return np.ascontiguousarray(data), int(sr)
+    except ImportError:
+        pass
+    except Exception:
+        return _decode_with_ffmpeg(path)
+    try:
+        from scipy.io import wavfile
+        sr, data = wavfile.read(path)
+        if data.dtype == np.float32:
+            a = data
+        elif data.dtype == np.int16:
+            a = data.astype(np.float32) / 32768.0
+        elif data.dtype == np.int32:
+            a = data.astype(np.float32) / 2147483648.0
+        elif data.dtype == np.uint8:
+            a = (data.astype(np.float32) - 128.0) / 128.0
+        else:
+            a = data.astype(np.float32)
+        if a.ndim == 1:
+            a = a[:, None]
+        return np.ascontiguousarray(a), int(sr)
+    except Exception:
+        pass
+    try:
+        return _read_wav_stdlib(path)
+    except Exception:
+        return _decode_with_ffmpeg(path)
+
+
+def _decode_with_ffmpeg(path, target_sr=48000):
+    ffmpeg = shutil.which("ffmpeg")
+    if ffmpeg is None:
+        raise RuntimeError("ffmpeg not found for decoding non-WAV formats.")
+    cmd = [ffmpeg, "-v", "error", "-i", path, "-f", "f32le", "-acodec", "pcm_f32le", "-ac", "1",
+           "-ar", str(int(target_sr)), "-"]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if proc.returncode != 0:
+        raise RuntimeError(f"ffmpeg decode failed: {proc.stderr.decode('utf-8', 'ignore')}")
+    return np.frombuffer(proc.stdout, dtype=np.float32).reshape(-1, 1).copy(), int(target_sr)
+
+
+# ----------------------------------------------------------------------------- renderer
+
+class HipOffscreenRenderer:
+    """Frame source with the reference renderer's constructor and duck type (exporter.py:98-122, :246-252)."""
+
+    def __init__(self, width, height, mode, color, sensitivity, fps, audio_path, **view_state):
+        self.width = int(width)
+        self.height = int(height)
+        self.mode = str(mode)
+        self.color = color
+        self.sensitivity = float(sensitivity or 1.0)
+        self.fps = int(fps)
+        self.audio_path = audio_path
+        self.view_state = dict(view_state)
+
+        kind = mode_kind(self.mode)
+        if kind not in SUPPORTED_KINDS:
+            raise NotImplementedError(f"mode {self.mode!r} is not implemented on the HIP export path yet")
+        for key in ("background_path", "glow_enabled", "shadow_enabled", "radial_fill_enabled"):
+            if view_state.get(key):
+                raise NotImplementedError(f"view_state[{key!r}] is not implemented on the HIP export path yet")
+
+        device = int(view_state.get("hip_device", 0) or 0)
+        self._eng = get_engine(device)
+        if isinstance(audio_path, (tuple, list)) and len(audio_path) == 2:      # (array, samplerate): tests/bench
+            audio, sr = audio_path
+        else:
+            audio, sr = load_audio(audio_path)
+        self._track = (self._eng.upload_track(audio, sr, self.fps) if isinstance(audio, np.ndarray)
+                       else self._eng.make_track(audio, sr, self.fps))
+        self.samplerate = int(sr)
+        self.duration = float(self._track.n_samples / self.samplerate)           # exporter.py:113
+        self.total_frames = self._track.total_frames
+        rng = view_state.get("hip_frame_range")
+        f0, f1 = (int(rng[0]), int(rng[1])) if rng else (0, self.total_frames)
+        self.frame_begin, self.frame_end = max(0, f0), min(self.total_frames, f1)
+        self._pipe = FramePipeline(self._eng, self._track, self.mode, self.width, self.height, self.sensitivity,
+                                   self.frame_begin, self.frame_end,
+                                   batch_frames=view_state.get("hip_batch_frames"))
+        self._cache = None          # (first_frame, uint8 [n, H, W, 3] host array)
+
+    # -- batched fast path used by Exporter._run_pipe ---------------------------------------------------
+    def stream_to(self, sink, progress=None):
+        return self._pipe.run(sink, progress)
+
+    # -- reference duck type ----------------------------------------------------------------------------
+    def render_frame_index(self, i: int) -> np.ndarray:
+        i = int(i)
+        if not (self.frame_begin <= i < self.frame_end):
+            raise IndexError(f"frame {i} outside [{self.frame_begin}, {self.frame_end})")
+        c = self._cache
+        if c is None or not (c[0] <= i < c[0] + c[1].shape[0]):
+            n = min(self._pipe.batch, self.frame_end - i)
+            frames = self._pipe.render_device(first=i - self.frame_begin, count=n)
+            c = self._cache = (i, frames.cpu().numpy())
+        return c[1][i - c[0]]
+
+    def render_frame(self, t):
+        return self.render_frame_index(int(round(float(t) * self.fps)))
+
+    def render_time(self, t):
+        return self.render_frame(t)
+
+
+# ----------------------------------------------------------------------------- ffmpeg utilities
+
+def _ffmpeg_bin() -> str:
+    """AURORA_FFMPEG, IMAGEIO_FFMPEG_EXE, imageio_ffmpeg, then PATH (exporter.py:319-341)."""
+    for var in ("AURORA_FFMPEG", "IMAGEIO_FFMPEG_EXE"):
+        cand = os.environ.get(var)
+        if cand and Path(cand).exists():
+            return cand
+    try:
+        import imageio_ffmpeg
+        cand = imageio_ffmpeg.get_ffmpeg_exe()
+        if cand and Path(cand).exists():
+            return cand
+    except Exception:
+        pass
+    found = shutil.which("ffmpeg")
+    if found:
+        return found
+    raise RuntimeError("FFmpeg not found. Install ffmpeg or pip install imageio-ffmpeg, "
+                       "or set AURORA_FFMPEG/IMAGEIO_FFMPEG_EXE.")
+
+
+def _ffmpeg_encoders(ffmpeg: str) -> set:
+    try:
+        listing = subprocess.check_output([ffmpeg, "-hide_banner", "-encoders"], stderr=subprocess.STDOUT,
+                                          text=True, errors="ignore")
+    except Exception:
+        return set()
+    names = set()
+    for line in listing.splitlines():
+        if line.startswith(" V"):
+            cols = line.split()
+            if len(cols) > 1:
+                names.add(cols[1].strip())
+    return names
+
+
+def _ensure_ext(path: str, default_ext: str) -> str:
+    return path if os.path.splitext(path)[1] else os.path.splitext(path)[0] + default_ext
+
+
+# encoder family -> (h264 name, hevc name, extra video flags)
+_HW = {
+    "videotoolbox": ("h264_videotoolbox", "hevc_videotoolbox", ["-b:v", "12M", "-maxrate", "20M", "-bufsize", "40M"]),
+    "nvenc": ("h264_nvenc", "hevc_nvenc", ["-preset", "p5", "-rc", "vbr", "-cq", "19", "-b:v", "0", "-maxrate", "0"]),
+    "vaapi": ("h264_vaapi", "hevc_vaapi", ["-b:v", "12M", "-maxrate", "20M", "-bufsize", "40M"]),
+    "qsv": ("h264_qsv", "hevc_qsv", ["-global_quality", "23"]),
+    "amf": ("h264_amf", "hevc_amf", ["-quality", "balanced"]),
+}
+
+
+def list_gpu_export_devices() -> List[Dict[str, str]]:
+    """Hardware video ENCODERS FFmpeg offers (UI dropdown, exporter.py:368-410)."""
+    enc = _ffmpeg_encoders(_ffmpeg_bin())
+    system = platform.system()
+
+    def has(fam):
+        return _HW[fam][0] in enc or _HW[fam][1] in enc
+
+    if system == "Darwin":
+        return [{"id": "videotoolbox", "label": "Apple VideoToolbox"}] if has("videotoolbox") else []
+    out: List[Dict[str, str]] = []
+    if has("nvenc"):
+        lines: List[str] = []
+        smi = shutil.which("nvidia-smi")
+        if smi:
+            try:
+                txt = subprocess.check_output([smi, "-L"], text=True, errors="ignore")
+                lines = [ln.strip() for ln in txt.splitlines() if ln.strip().startswith("GPU ")]
+            except Exception:
+                lines = []
+        if lines:
+            out += [{"id": f"nvenc:{k}", "label": f"NVIDIA NVENC ({ln})"} for k, ln in enumerate(lines)]
+        else:
+            out.append({"id": "nvenc:0", "label": "NVIDIA NVENC"})
+    if has("amf"):
+        out.append({"id": "amf:auto", "label": "AMD AMF"})
+    if has("qsv"):
+        out.append({"id": "qsv:auto", "label": "Intel Quick Sync (QSV)"})
+    if has("vaapi") and system == "Linux":
+        try:
+            for node in sorted(Path("/dev/dri").glob("renderD*")):
+                out.append({"id": f"vaapi:{node}", "label": f"VAAPI ({node.name})"})
+        except Exception:
+            pass
+    return out
+
+
+def build_ffmpeg_cmd(width: int, height: int, fps: int, out_path: str, audio_path: str,
+                     prefer_hevc: bool = False, gpu_device: Optional[str] = None) -> Tuple[List[str], str]:
+    """FFmpeg argv for rawvideo rgb24 WxH@fps on stdin + the audio file (exporter.py:413-491)."""
+    out_path = _ensure_ext(out_path, ".mp4")
+    ffmpeg = _ffmpeg_bin()
+    enc = _ffmpeg_encoders(ffmpeg)
+    system = platform.system()
+
+    dev = (gpu_device or "").strip()
+    if dev.lower() in {"", "0", "false", "off", "no", "cpu"}:
+        dev = ""
+    elif dev.lower() == "auto":
+        choices = list_gpu_export_devices()
+        dev = choices[0]["id"] if choices else ""
+
+    argv: List[str] = [ffmpeg, "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{width}x{height}",
+                       "-r", str(int(fps)), "-i", "pipe:0", "-i", audio_path]
+    fam = dev.split(":", 1)[0] if dev else ""
+    arg = dev.split(":", 1)[1] if ":" in dev else ""
+    usable = (fam in _HW and (_HW[fam][0] in enc or _HW[fam][1] in enc)
+              and (fam != "videotoolbox" or system == "Darwin") and (fam != "vaapi" or system == "Linux")
+              and (fam == "videotoolbox" or ":" in dev))
+    pix_out, vfilter = "yuv420p", None
+    if usable:
+        h264, hevc, flags = _HW[fam]
+        codec = hevc if (prefer_hevc and hevc in enc) else h264
+        if codec not in enc:
+            raise RuntimeError(f"Hardware encoder not available: {codec}")
+        vflags = list(flags)
+        if fam == "nvenc":
+            try:
+                idx = int(arg)
+            except Exception:
+                idx = 0
+            vflags = ["-gpu", str(idx)] + vflags
+        elif fam == "vaapi":
+            argv += ["-vaapi_device", arg]
+            vfilter, pix_out = "format=nv12,hwupload", "nv12"
+    else:
+        codec, vflags = "libx264", ["-preset", "veryfast", "-crf", "20"]
+    if vfilter:
+        argv += ["-vf", vfilter]
+    argv += ["-c:v", codec, *vflags, "-pix_fmt", pix_out, "-c:a", "aac", "-b:a", "192k", "-shortest", out_path]
+    return argv, "rgb24"
+
+
+# ----------------------------------------------------------------------------- exporter
+
+class _PipeSink:
+    def __init__(self, stdin):
+        self._stdin = stdin
+
+    def write(self, buf):
+        self._stdin.write(buf)
+
+
+class Exporter:
+    def __init__(self, audio_path, width=1920, height=1080, fps=60, mode="Waveform - Linear",
+                 color=(0.2, 0.8, 1.0), sensitivity=1.0, prefer_hevc=False, view_state=None,
+                 gpu_rendering=False, gpu_device=None):
+        self.audio_path = audio_path
+        self.width = int(width)
+        self.height = int(height)
+        self.fps = int(fps)
+        self.mode = str(mode)
+        self.color = tuple(color)
+        self.sensitivity = float(sensitivity)
+        self.prefer_hevc = bool(prefer_hevc)
+        self.view_state = view_state or {}
+        self.gpu_rendering = bool(gpu_rendering)
+        self.gpu_device = gpu_device or ("auto" if self.gpu_rendering else "")
+
+    def make_renderer(self):
+        return HipOffscreenRenderer(self.width, self.height, self.mode, self.color, self.sensitivity, self.fps,
+                                    self.audio_path, **self.view_state)
+
+    def render_to_file(self, out_path, progress_cb=None):
+        renderer = self.make_renderer()
+        logger.info("Export using HIP renderer on MI355X (device %s)", self.view_state.get("hip_device", 0))
+        cmd, _ = build_ffmpeg_cmd(self.width, self.height, self.fps, out_path, self.audio_path,
+                                  prefer_hevc=self.prefer_hevc, gpu_device=self.gpu_device)
+        return self._run_pipe(renderer, cmd, progress_cb=progress_cb)
+
+    def render_to_sink(self, sink, progress_cb=None):
+        """Same frame stream as render_to_file, into any object with write(buffer) (tests, benchmarks, raw files)."""
+        renderer = self.make_renderer()
+        return self._pump(renderer, sink, progress_cb)
+
+    def _pump(self, renderer, sink, progress_cb):
+        total_frames = int(np.ceil(renderer.duration * self.fps)) if hasattr(renderer, "duration") else 0   # :536
+        step = max(1, int(self.fps / 2))                                                                   # :545
+
+        def _tick(i):
+            if progress_cb and (i % step == 0):
+                try:
+                    progress_cb(int(i * 100 / total_frames) if total_frames else 0)
+                except Exception:
+                    pass
+
+        if hasattr(renderer, "stream_to"):
+            seen = [getattr(renderer, "frame_begin", 0)]
+
+            def on_batch(done, _n):
+                upto = getattr(renderer, "frame_begin", 0) + done
+                for i in range(seen[0], upto):
+                    _tick(i)
+                seen[0] = upto
+
+            return renderer.stream_to(sink, on_batch)
+        written = 0
+        for i in range(total_frames):                      # generic duck-typed renderer: the reference loop
+            frame = np.ascontiguousarray(renderer.render_time(i / self.fps))
+            try:
+                sink.write(memoryview(frame).cast("B"))
+            except BrokenPipeError:
+                break
+            written += 1
+            _tick(i)
+        return written
+
+    def _run_pipe(self, renderer, cmd, progress_cb=None):
+        proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                bufsize=10 ** 7)
+        try:
+            self._pump(renderer, _PipeSink(proc.stdin), progress_cb)
+        finally:
+            try:
+                if proc.stdin:
+                    proc.stdin.close()
+            except Exception:
+                pass
+        try:
+            stderr = proc.stderr.read().decode("utf-8", errors="ignore") if proc.stderr else ""
+        except Exception:
+            stderr = ""
+        code = proc.wait()
+        if progress_cb:
+            try:
+                progress_cb(100)
+            except Exception:
+                pass
+        if code != 0:
+            raise RuntimeError(f"ffmpeg failed (exit {code}):\n{stderr}")

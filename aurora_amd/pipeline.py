@@ -1,0 +1,183 @@
+"""Frame pipeline: analysis -> scan -> rasterise in batches on the GPU, pinned async readback on a side
+stream, ordered hand-off to a sink (FFmpeg stdin, a file, or a null sink) from a writer thread.
+
+Replaces the per-frame loop of export/exporter.py:538-549 and its three host copies
+(``arr.copy()`` :95, ``tobytes()`` :542, pipe write): frames leave the GPU once, into page-locked memory,
+and are written to the sink straight from there.
+
+Time sharding (one process per GPU): a pipeline renders frames ``[frame_begin, frame_end)`` of a track.  The
+analysis halo (previous block / previous magnitudes) is rebuilt inside the STFT kernel; the carried smoothing
+state (colour EMA, flux EMA, phase) comes from an analysis-only pre-pass over ``[0, frame_begin)``
+(``HipExportEngine.carried_state``), so a shard's bytes are identical to the same frames of an unsharded run.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import queue
+import threading
+
+import numpy as np
+
+from . import _lib
+from .engine import HipExportEngine, Track, mode_kind, SUPPORTED_KINDS
+
+
+class NullSink:
+    """Counts bytes; stands in for FFmpeg in benchmarks (FFmpeg is excluded on both CPU and GPU sides)."""
+
+    def __init__(self):
+        self.bytes = 0
+        self.frames = 0
+
+    def write(self, buf):
+        self.bytes += len(buf)
+
+    def close(self):
+        pass
+
+
+class FileSink:
+    def __init__(self, path):
+        self._f = open(path, "wb")
+
+    def write(self, buf):
+        self._f.write(buf)
+
+    def close(self):
+        self._f.close()
+
+
+class _PinnedSlot:
+    def __init__(self, lib, nbytes):
+        self.lib = lib
+        p = C.c_void_p()
+        _lib.check(lib.aur_host_alloc(C.byref(p), nbytes), "aur_host_alloc")
+        self.ptr = p
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def free(self):
+        if self.ptr:
+            self.lib.aur_host_free(self.ptr)
+            self.ptr = None
+
+
+def default_batch_frames(W: int, H: int, budget_bytes: int = 1 << 30) -> int:
+    """Frames per batch so one device slot is about ``budget_bytes`` (at least 8, at most 1024 frames)."""
+    return int(max(8, min(1024, budget_bytes // (W * H * 3))))
+
+
+class FramePipeline:
+    def __init__(self, engine: HipExportEngine, track: Track, mode: str, width: int, height: int,
+                 sensitivity: float = 1.0, frame_begin: int = 0, frame_end: int | None = None,
+                 batch_frames: int | None = None, slots: int = 2, scan_params: _lib.ScanParams | None = None):
+        self.eng = engine
+        self.track = track
+        self.mode = mode
+        self.kind = mode_kind(mode)
+        if self.kind not in SUPPORTED_KINDS:
+            raise NotImplementedError(f"mode {mode!r} ({self.kind}) is not implemented on the HIP path yet")
+        self.W, self.H = int(width), int(height)
+        self.frame_begin = int(frame_begin)
+        self.frame_end = track.total_frames if frame_end is None else int(frame_end)
+        if not (0 <= self.frame_begin <= self.frame_end <= track.total_frames):
+            raise ValueError("bad frame range")
+        self.batch = int(batch_frames or default_batch_frames(self.W, self.H))
+        self.slots = int(max(1, slots))
+        self.params = scan_params or _lib.ScanParams.defaults(sensitivity)
+        self.frame_bytes = self.W * self.H * 3
+        self._analysed = None
+
+    # ---- phase 1: analysis + scan of the whole shard (about 10 KB per frame) -------------------------
+    def analyse(self):
+        if self._analysed is None:
+            eng = self.eng
+            state = eng.carried_state(self.track, self.frame_begin, self.params) if self.frame_begin > 0 else None
+            n = self.frame_end - self.frame_begin
+            an = eng.analyze(self.track, self.frame_begin, n, want_samples=(self.kind == "waveform_linear"))
+            sc = eng.scan(an, self.params, state)
+            self._analysed = (an, sc)
+        return self._analysed
+
+    # ---- device-only rendering (benchmark "value": frames stay in HBM) ----------------------------------
+    def render_device(self, out=None, spans_out=None, first: int = 0, count: int | None = None):
+        an, sc = self.analyse()
+        return self.eng.render(self.mode, an, sc, self.W, self.H, first, count, out=out, spans_out=spans_out)
+
+    # ---- full pipeline: GPU -> pinned host ring -> sink --------------------------------------------------
+    def run(self, sink, progress=None):
+        """Renders every frame of the shard in order into ``sink.write``.  Returns the number of frames."""
+        eng, torch = self.eng, self.eng.torch
+        an, sc = self.analyse()
+        n_total = self.frame_end - self.frame_begin
+        if n_total == 0:
+            return 0
+        B, S = min(self.batch, n_total), self.slots
+        K = {"spectrum_linear": _lib.K_SPECTRUM, "particles": _lib.K_PARTICLES,
+             "waveform_linear": _lib.K_WAVEFORM}[self.kind]
+        dev_frames = [eng.empty((B, self.H, self.W, 3), torch.uint8) for _ in range(S)]
+        dev_spans = [eng.empty((B, K, self.W), torch.int32) for _ in range(S)]
+        host = [_PinnedSlot(eng.lib, B * self.frame_bytes) for _ in range(S)]
+        copy_stream = torch.cuda.Stream(device=eng.device)
+        copied = [None] * S                    # event: slot's D2H copy finished
+        free_slots = threading.Semaphore(S)    # host slot consumed by the writer
+        q: "queue.Queue" = queue.Queue()
+        err = []
+
+        def writer():
+            try:
+                while True:
+                    item = q.get()
+                    if item is None:
+                        return
+                    slot, nframes, ev, first = item
+                    ev.synchronize()
+                    if not err:
+                        try:
+                            sink.write(memoryview(host[slot].array)[:nframes * self.frame_bytes])
+                        except BrokenPipeError as e:          # exporter.py:543-544: stop writing
+                            err.append(e)
+                    free_slots.release()
+                    if progress is not None and not err:
+                        progress(first + nframes, n_total)
+            except BaseException as e:   # keep the producer from blocking forever
+                err.append(e)
+                free_slots.release()
+
+        th = threading.Thread(target=writer, name="aurora-sink-writer", daemon=True)
+        th.start()
+        done = 0
+        try:
+            i = 0
+            while done < n_total and not err:
+                slot = i % S
+                n = min(B, n_total - done)
+                free_slots.acquire()                       # host slot drained by the writer
+                if err:
+                    free_slots.release()
+                    break
+                cur = torch.cuda.current_stream(eng.device)
+                if copied[slot] is not None:
+                    cur.wait_event(copied[slot])           # device slot no longer being read by the copy engine
+                eng.render(self.mode, an, sc, self.W, self.H, done, n, out=dev_frames[slot][:n],
+                           spans_out=dev_spans[slot][:n])
+                rendered = torch.cuda.Event()
+                rendered.record(cur)
+                copy_stream.wait_event(rendered)
+                _lib.check(eng.lib.aur_readback_async(eng.ctx.handle, C.c_void_p(dev_frames[slot].data_ptr()),
+                                                      n * self.frame_bytes, host[slot].ptr,
+                                                      C.c_void_p(copy_stream.cuda_stream)), "aur_readback_async")
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+                copied[slot] = ev
+                q.put((slot, n, ev, done))
+                done += n
+                i += 1
+        finally:
+            q.put(None)
+            th.join()
+            torch.cuda.synchronize(eng.device)
+            for h in host:
+                h.free()
+        if err and not isinstance(err[0], BrokenPipeError):
+            raise err[0]
+        return done

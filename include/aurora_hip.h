@@ -1,0 +1,169 @@
+/*
+ * aurora_hip.h -- C ABI of libaurora_hip.so: the MI355X (gfx950) implementation of Aurora's
+ * offline-export hot path (per-frame STFT analysis + per-frame RGB24 rasterisation).
+ *
+ * The reference (Strepto-Code/Aurora) is pure Python and has no FFI of its own; the boundary it
+ * exposes is its Python API (audio/analysis.py, export/exporter.py, export/worker.py).  The host
+ * side in aurora_amd/ keeps those signatures and reaches the kernels through the entry points
+ * below via ctypes.  Each entry point names the reference code it replaces (paths relative to the
+ * reference root).
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative AUR_E* code on failure; aur_last_error()
+ *    returns a thread-local message for the last failure on the calling thread;
+ *  - nothing throws across the ABI; no torch types; all pointers named d_* are DEVICE pointers
+ *    (e.g. torch.Tensor.data_ptr()), h_* are HOST pointers; the caller owns every buffer;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); all launches are
+ *    asynchronous on that stream; no entry point except aur_create/aur_destroy/aur_host_* allocates
+ *    or synchronises;
+ *  - a context (aur_ctx) belongs to one device; use one context per device per thread.
+ */
+#ifndef AURORA_HIP_H
+#define AURORA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUR_OK            0
+#define AUR_EINVAL       -1   /* bad argument (shape, size, null pointer, unsupported value) */
+#define AUR_EHIP         -2   /* a HIP runtime call failed (message holds hipGetErrorString) */
+#define AUR_ENOMEM       -3
+#define AUR_EUNSUPPORTED -4
+
+#define AUR_FFT_SIZE   2048   /* audio/analysis.py:6, export/exporter.py:114 (always 2048 in export) */
+#define AUR_BLOCK      1024   /* Analyzer.hop, audio/analysis.py:13; samples per frame, exporter.py:235 */
+#define AUR_NBINS      1025   /* fft_size/2+1, audio/analysis.py:10 */
+#define AUR_N_BARS       80   /* widgets/rt_widget.py:935 */
+#define AUR_N_PARTICLES  50   /* widgets/rt_widget.py:991 */
+
+/* span slots per pixel column (see aur_spans_*) */
+#define AUR_K_SPECTRUM    2
+#define AUR_K_PARTICLES   2
+#define AUR_K_WAVEFORM    5
+
+typedef struct aur_ctx aur_ctx;
+
+/* ---- library / context --------------------------------------------------------------------- */
+
+int         aur_version(void);                 /* ABI version, bumped on incompatible change */
+const char* aur_last_error(void);              /* thread-local, never NULL */
+int         aur_device_count(int* out_count);
+
+/* Creates a context on `device`: uploads the Hann window (audio/analysis.py:9) and the FFT twiddle
+ * tables (computed in float64, rounded to float32).  Replaces Analyzer.__init__ (analysis.py:6-14). */
+int  aur_create(int device, aur_ctx** out);
+void aur_destroy(aur_ctx* ctx);
+
+/* Copies the float32[2048] analysis window held by the context to the host (parity tests compare it
+ * with scipy.signal.get_window('hann', 2048, fftbins=True).astype(float32)). */
+int  aur_get_window(aur_ctx* ctx, float* h_window /*[2048]*/);
+
+/* ---- analysis: replaces _read_frame + Analyzer.compute --------------------------------------- */
+
+/* Fused per-frame analysis for frames [frame_begin, frame_begin + n_frames) of one track.
+ *
+ * Replaces, per frame f (reference: export/exporter.py:227-238 `_read_frame`, audio/analysis.py:16-33
+ * `Analyzer.compute`, widgets/rt_widget.py:824 energy):
+ *   samples  = zeros(1024); samples[:n] = mono(audio[pos[f] : pos[f]+hop])[:1024]      (mono = channel mean)
+ *   buffer   = [samples(f-1) | samples(f)]   (samples(-1) = 0)      -> * periodic Hann -> rfft(2048) -> |X|
+ *   d_logspec[f]   = log1p(|X|)                       float32[1025]   (optional, NULL to skip)
+ *   d_flux_sum[f]  = sum(max(0, |X|(f) - |X|(f-1)))   float32  (|X|(-1) = 0; Analyzer.compute divides by 1025)
+ *   d_meanabs[f]   = mean(|samples|)                  float32, numpy pairwise-summation order (bit-exact)
+ *   d_samples[f]   = samples                          float32[1024]   (optional, NULL to skip)
+ *   d_bandmax[f]   = (max(logspec[:80]), max(logspec[:50]))  float32[2] (optional, NULL to skip)
+ * Output arrays are indexed by (f - frame_begin).  The sliding-buffer / flux history of frames before
+ * frame_begin is rebuilt from the audio itself (time-shard halo), so any frame range gives the same
+ * values as a run from frame 0.
+ *
+ * d_audio  : float32 [n_samples, channels] interleaved (soundfile layout); channels must be 1 or 2.
+ * d_pos    : int64 [n_track_frames] sample position of EVERY frame of the track (exporter.py:230),
+ *            computed on the host in float64; entries frame_begin-2 .. frame_begin+n_frames-1 are read.
+ * hop      : max(1, int(sr/fps)) (exporter.py:229).
+ */
+int aur_stft_frames(aur_ctx* ctx,
+                    const float* d_audio, int64_t n_samples, int channels,
+                    const int64_t* d_pos, int64_t frame_begin, int n_frames, int hop,
+                    float* d_logspec, float* d_flux_sum, float* d_meanabs,
+                    float* d_samples, float* d_bandmax, void* stream);
+
+/* One streaming Analyzer.compute step (audio/analysis.py:25-33) for callers that keep Analyzer.buffer
+ * themselves (the realtime caller audio/input.py:276-293 and the drop-in Analyzer.compute):
+ *   windowed = buffer * window; mag = |rfft(windowed)|; d_flux_sum[0] = sum(max(0, mag - prev_mag));
+ *   d_prev_mag <- mag (in place); d_logspec = log1p(mag).
+ * d_buffer: float32[2048] already slid by the caller (analysis.py:18-23); d_prev_mag: float32[1025] in/out. */
+int aur_stft_buffer(aur_ctx* ctx, const float* d_buffer, float* d_prev_mag, float* d_logspec,
+                    float* d_flux_sum, void* stream);
+
+/* ---- smoothing scan over frames --------------------------------------------------------------- */
+
+typedef struct aur_scan_params {
+    double sensitivity;      /* RTVisualizerWidget.waveform_sensitivity (rt_widget.py:140-145), >= 0.05 */
+    double amp_alpha;        /* _amp_alpha = 0.2 (rt_widget.py:57, :487) */
+    double grad_min;         /* _grad_min = 0.0 (rt_widget.py:54) */
+    double grad_max;         /* _grad_max = 1.0 (rt_widget.py:55) */
+    int    grad_curve;       /* 0 linear, 1 ease-in, 2 ease-out, 3 smoothstep (rt_widget.py:490-495) */
+    uint8_t grad_a[4];       /* (32,255,255) rt_widget.py:51 */
+    uint8_t grad_b[4];       /* (255,0,255)  rt_widget.py:52 */
+    double flux_alpha;       /* Analyzer.flux_alpha = 0.9 (analysis.py:12) */
+    /* carried state at the first frame of this call (0 at track start); updated on return path via d_state_out */
+    double amp_ema0;
+    double flux_smooth0;
+    double phase0;
+} aur_scan_params;
+
+/* Sequential-order (bit-exact, float64) recurrences over n_frames consecutive frames:
+ *   energy[f]      = float(clip(float32(meanabs[f]) * sensitivity, 0, 1))              rt_widget.py:824
+ *   amp_ema        = amp_alpha*amp_ema + (1-amp_alpha)*energy[f]  -> pen_rgb[f]         rt_widget.py:485-499
+ *   flux_smooth[f] = flux_alpha*flux_smooth + (1-flux_alpha)*(flux_sum[f]/1025)         analysis.py:29-30
+ *   phase[f]       = (phase + 0.04*(0.5+energy[f])) % (2*pi)                            rt_widget.py:825
+ * d_pen_rgb: uint8 [n_frames,4] (r,g,b,0).  d_state_out: float64[3] = (amp_ema, flux_smooth, phase) after the
+ * last frame (carried smoothing state for the next time shard); may be NULL.  Any output may be NULL.
+ */
+int aur_scan_frames(aur_ctx* ctx, const float* d_meanabs, const float* d_flux_sum, int n_frames,
+                    const aur_scan_params* params,
+                    double* d_energy, uint8_t* d_pen_rgb, double* d_flux_smooth, double* d_phase,
+                    double* d_state_out, void* stream);
+
+/* ---- rasteriser -------------------------------------------------------------------------------- */
+
+/* Column spans: uint32 [n_frames, K, W]; element = r0 | (r1 << 16), a half-open lit row interval
+ * [r0, r1) of that pixel column (0 = empty).  W, H <= 16384; W >= 160.                              */
+
+/* `_draw_spectrum` linear branch (rt_widget.py:934-940, :982-988): 80 vertical width-2 lines. K = 2. */
+int aur_spans_spectrum_linear(aur_ctx* ctx, const float* d_logspec /*[F,1025]*/, const double* d_energy /*[F]*/,
+                              int n_frames, int W, int H, uint32_t* d_spans, void* stream);
+
+/* `_draw_particles` (rt_widget.py:990-1000): 50 width-2 points. K = 2. */
+int aur_spans_particles(aur_ctx* ctx, const float* d_logspec, int n_frames, int W, int H,
+                        uint32_t* d_spans, void* stream);
+
+/* `_draw_waveform` linear branch (rt_widget.py:903-913, :932): width-2 SquareCap/BevelJoin polyline through
+ * (x, mid - samples[col2samp[x]]*amp).  d_col2samp: int32[W] = int((x/max(1,W-1))*(1023)) computed on the host
+ * in float64 (rt_widget.py:908).  K = 5. */
+int aur_spans_waveform_linear(aur_ctx* ctx, const float* d_samples /*[F,1024]*/, const int32_t* d_col2samp,
+                              const double* d_energy, int n_frames, int W, int H, uint32_t* d_spans, void* stream);
+
+/* Fills n_frames RGB24 frames (uint8 [F,H,W,3], tightly packed = `_qimage_to_numpy` output, exporter.py:84-95,
+ * i.e. the rawvideo rgb24 wire format of build_ffmpeg_cmd, exporter.py:429-434): background (13,13,18)
+ * (rt_widget.py:829), pen colour d_pen_rgb[f] on every pixel inside a span.                           */
+int aur_raster_spans(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb /*[F,4]*/,
+                     int n_frames, int W, int H, uint8_t* d_frames, void* stream);
+
+/* ---- readback ---------------------------------------------------------------------------------- */
+
+/* Pinned host memory for the frame ring that feeds the FFmpeg pipe (replaces the arr.copy()/tobytes()
+ * chain of exporter.py:95, :540-542). */
+int aur_host_alloc(void** out, size_t bytes);
+int aur_host_free(void* p);
+/* hipMemcpyAsync device->host on `stream`. */
+int aur_readback_async(aur_ctx* ctx, const void* d_src, size_t bytes, void* h_dst, void* stream);
+int aur_stream_synchronize(aur_ctx* ctx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AURORA_HIP_H */

@@ -1,0 +1,163 @@
+"""CPU-only tests: host logic against the oracle, C-ABI library load/exports, raster oracle self-consistency."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from aurora_amd import _lib, engine, synth
+from oracle import analysis_ref as A
+from oracle import raster_ref as R
+
+
+# ------------------------------------------------------------------ index maps must be bit-exact
+
+@pytest.mark.parametrize("n,sr,fps", [(48000 * 240, 48000, 60), (44100 * 30, 44100, 30), (22173, 44100, 60),
+                                      (500, 48000, 60), (30000, 48000, 24), (48000 * 3600, 48000, 60)])
+def test_frame_plan_matches_oracle(n, sr, fps):
+    hop, total, pos = engine.frame_plan(n, sr, fps)
+    if total > 20000:       # python-loop oracle on a prefix + tail only
+        t = np.concatenate([np.arange(5000), np.arange(total - 5000, total)])
+        want = np.array([int(max(0, min(n - 1, (i / fps) * sr))) for i in t], dtype=np.int64)
+        assert np.array_equal(pos[t], want)
+        assert hop == max(1, int(sr / fps)) and total == int(np.ceil(float(n / sr) * fps))
+    else:
+        hop_o, total_o, pos_o = A.frame_plan(n, sr, fps)
+        assert (hop, total) == (hop_o, total_o)
+        assert np.array_equal(pos, pos_o)
+
+
+@pytest.mark.parametrize("w", [160, 1000, 1280, 1920, 3840])
+def test_col2samp_matches_oracle(w):
+    assert np.array_equal(engine.waveform_col2samp(w), R.waveform_col2samp(w))
+
+
+def test_mode_dispatch():
+    for m in ("Spectrum - Linear", "Spectrum - Radial", "Waveform - Linear", "Waveform - Circular", "Particles", ""):
+        assert engine.mode_kind(m) == R.mode_kind(m)
+
+
+# ------------------------------------------------------------------ C ABI library
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(REPO, "include", "aurora_hip.h")).read()
+    declared = set(re.findall(r"\b(aur_[a-z_0-9]+)\s*\(", header))
+    declared -= {"aur_ctx", "aur_scan_params"}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.aur_version() == _lib.ABI_VERSION
+    assert isinstance(lib.aur_last_error(), bytes)
+
+
+def test_scan_params_layout_matches_header():
+    # struct aur_scan_params: 4 doubles, int, 2x uint8[4], (pad), 4 doubles
+    assert ctypes.sizeof(_lib.ScanParams) == 80
+    assert _lib.ScanParams.grad_curve.offset == 32
+    assert _lib.ScanParams.grad_a.offset == 36 and _lib.ScanParams.grad_b.offset == 40
+    assert _lib.ScanParams.flux_alpha.offset == 48 and _lib.ScanParams.phase0.offset == 72
+
+
+def test_error_paths_without_gpu():
+    lib = _lib.load()
+    assert lib.aur_device_count(None) == -1
+    assert b"null" in lib.aur_last_error()
+    assert lib.aur_stft_frames(None, None, 0, 2, None, 0, 1, 800, None, None, None, None, None, None) != 0
+
+
+# ------------------------------------------------------------------ raster oracle: spans == brute-force coverage
+
+def _brute_polyline(Y, w, h):
+    """Pixel-centre-in-stroke-outline test written directly from the coverage rule (independent of the
+    interval algebra in spans_polyline): rectangles with square caps + bevel triangles."""
+    img = np.zeros((h, w), dtype=bool)
+    py, px = np.mgrid[0:h, 0:w]
+    cx, cy = px + 0.5, py + 0.5
+    P = [(float(x), float(Y[x])) for x in range(w)]
+    for s in range(w - 1):
+        (x0, y0), (x1, y1) = P[s], P[s + 1]
+        dx, dy = x1 - x0, y1 - y0
+        L = np.hypot(dx, dy)
+        ux, uy = dx / L, dy / L
+        rx, ry = cx - x0, cy - y0
+        along = rx * ux + ry * uy
+        across = -rx * uy + ry * ux
+        lo = -1.0 if s == 0 else 0.0
+        hi = L + (1.0 if s == w - 2 else 0.0)
+        img |= (along >= lo) & (along <= hi) & (np.abs(across) <= 1.0)
+    for v in range(1, w - 1):
+        dA = np.array([1.0, Y[v] - Y[v - 1]])
+        dB = np.array([1.0, Y[v + 1] - Y[v]])
+        cr = dA[0] * dB[1] - dA[1] * dB[0]
+        if cr == 0:
+            continue
+        sg = -1.0 if cr > 0 else 1.0
+        nA = sg * np.array([-dA[1], dA[0]]) / np.hypot(*dA)
+        nB = sg * np.array([-dB[1], dB[0]]) / np.hypot(*dB)
+        p0 = np.array([float(v), float(Y[v])])
+        p1, p2 = p0 + nA, p0 + nB
+
+        def side(a, b):
+            return (b[0] - a[0]) * (cy - a[1]) - (b[1] - a[1]) * (cx - a[0])
+
+        d0, d1, d2 = side(p0, p1), side(p1, p2), side(p2, p0)
+        img |= ((d0 >= 0) & (d1 >= 0) & (d2 >= 0)) | ((d0 <= 0) & (d1 <= 0) & (d2 <= 0))
+    return img
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_polyline_spans_equal_brute_force(seed):
+    rng = np.random.default_rng(seed)
+    w, h = 200, 120
+    # irrational-ish coordinates so no pixel centre sits on an outline edge (ties are measure zero)
+    Y = (h / 2 + np.cumsum(rng.standard_normal(w) * [0.3, 3.0, 12.0][seed]) + 0.1234567).astype(np.float32).astype(np.float64)
+    Y = np.clip(Y, -20, h + 20)
+    spans = R.spans_polyline(Y, w, h)
+    got = np.zeros((h, w), dtype=bool)
+    for x in range(w):
+        for k in range(spans.shape[1]):
+            got[spans[x, k, 0]:spans[x, k, 1], x] = True
+    want = _brute_polyline(Y, w, h)
+    assert np.array_equal(got, want), int(np.sum(got != want))
+
+
+def test_flat_waveform_and_bar_rules():
+    w, h = 320, 200
+    sp = R.spans_polyline(np.full(w, h / 2.0), w, h)
+    f = R.rasterize_spans(sp, (255, 0, 0), w, h)
+    lit = (f != np.array(R.BG, np.uint8)).any(axis=2)
+    assert lit[h // 2 - 1].all() and lit[h // 2].all() and lit.sum() == 2 * w     # silence: 2-px line, full width
+    spec = np.zeros(1025, np.float32)
+    spec[3] = 2.0
+    s2 = R.spans_spectrum_linear(spec, 1.0, w, h)
+    f2 = R.rasterize_spans(s2, (1, 2, 3), w, h)
+    lit2 = (f2 != np.array(R.BG, np.uint8)).any(axis=2)
+    bw = w // 80
+    assert lit2[:, 3 * bw].sum() == (h - 10) + 2 and lit2[:, 3 * bw - 1].sum() == (h - 10) + 2   # full bar + caps
+    assert lit2[:, 0].sum() == 2 and lit2[:, 1].sum() == 0                                       # bh = 0 -> 2x2 dot, half clipped
+    assert lit2[h - 5, 3 * bw] and not lit2[h - 4, 3 * bw]
+
+
+# ------------------------------------------------------------------ worker protocol (setup failures need no GPU)
+
+def test_worker_setup_errors(capsys, tmp_path):
+    from aurora_amd.export import worker
+    assert worker.main(["worker.py"]) == 2
+    assert json.loads(capsys.readouterr().out.strip())["message"] == "Missing config path"
+    assert worker.main(["worker.py", str(tmp_path / "nope.json")]) == 2
+    assert json.loads(capsys.readouterr().out.strip())["type"] == "error"
+    bad = tmp_path / "bad.json"
+    bad.write_text("{not json")
+    assert worker.main(["worker.py", str(bad)]) == 2
+    assert "Invalid config JSON" in json.loads(capsys.readouterr().out.strip())["message"]
+
+
+def test_synth_shapes():
+    a = synth.sweep(4410, 44100)
+    b = synth.pink(4800, 2)
+    assert a.shape == (4410, 2) and a.dtype == np.float32 and abs(float(np.max(np.abs(a))) - 0.8) < 1e-3
+    assert b.shape == (4800, 2) and abs(float(np.max(np.abs(b[:, 0]))) - 0.8) < 1e-6

@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X export hot path (BASELINE.json metric: exported frames/s, 4K60 spectrum mode; STFT GB/s).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (per GPU, per step): one unit of BASELINE.json configs[4] -- a 1 h, 48 kHz, stereo synthetic pink-noise
+track exported in "Spectrum - Linear" mode at 3840x2160@60 = 216 000 frames.  A step runs the whole device path
+over that track: fused STFT analysis (1 launch) -> smoothing scan -> column spans -> RGB24 fill of every frame
+into a ring of device slots (frames stay in HBM; the PCIe-inclusive rate is measured separately and reported as
+`pcie_inclusive_fps`, never as `value`).  Ranks take different tracks (time/track sharding, no collective): weak
+scaling, value = N * frames / max-over-ranks step time.
+
+The JSON line also carries
+  roofline      : the dominant kernel (raster fill), algorithmic bytes W*H*3 per frame / HIP-event time
+  roofline_stft : the fused STFT kernel, algorithmic bytes 4*C*min(hop,1024) + 4*1025 + 8 per frame
+  cpu_baseline  : the numpy oracle (a port of the reference's CPU path) timed on one host core over a bounded
+                  sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=3600.0, help="track length per GPU per step")
+    ap.add_argument("--sample-rate", type=int, default=48000)
+    ap.add_argument("--fps", type=int, default=60)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--mode", default="Spectrum - Linear")
+    ap.add_argument("--batch", type=int, default=128, help="frames per raster launch (device slot size)")
+    ap.add_argument("--cpu-frames", type=int, default=240, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--pcie-frames", type=int, default=1024, help="frames of the PCIe-inclusive leg (0 = skip)")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
+                    help="per-launch HBM bytes from separate rocprofv3 --pmc passes (see profiles/README.md)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle (port of export/exporter.py:538-544 + rt_widget.py paint_frame) on one host core."""
+    import numpy as np
+    from aurora_amd import synth
+    from oracle import analysis_ref as A      # checker / baseline only
+    from oracle import raster_ref as R
+
+    sr, fps, W, H = args.sample_rate, args.fps, args.width, args.height
+    n = int(args.cpu_frames * sr / fps)
+    audio = synth.pink(n, 2, seed=1234)
+    sunk = 0
+    t0 = time.perf_counter()
+    ref = A.analyze_track(audio, sr, fps)
+    pen, _ = A.amp_to_color_track(ref["energy"])
+    F = ref["samples"].shape[0]
+    for f in range(F):
+        frame = R.render_frame(args.mode, ref["samples"][f], ref["logspec"][f], float(ref["energy"][f]), pen[f], W, H)
+        frame = np.ascontiguousarray(frame)            # exporter.py:540
+        sunk += len(frame.tobytes())                   # exporter.py:542 -> null sink
+    dt = time.perf_counter() - t0
+    return {"value": F / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {F} frames ({F / fps:.1f} s of audio) of the same workload: numpy oracle analysis + "
+                      f"software rasteriser + ascontiguousarray/tobytes into a null sink, {dt:.1f} s on 1 core "
+                      f"of {os.cpu_count()} visible"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from aurora_amd import _lib, synth
+    from aurora_amd.engine import get_engine, mode_kind
+    from aurora_amd.pipeline import FramePipeline, NullSink
+
+    eng = get_engine(local_rank)
+    sr, fps, W, H = args.sample_rate, args.fps, args.width, args.height
+    n_samples = int(round(args.seconds * sr))
+    audio = synth.pink_device(n_samples, 2, 1234 + rank, device)      # input resident in HBM before timing
+    track = eng.make_track(audio, sr, fps)
+    F = track.total_frames
+    kind = mode_kind(args.mode)
+    K = {"spectrum_linear": _lib.K_SPECTRUM, "particles": _lib.K_PARTICLES, "waveform_linear": _lib.K_WAVEFORM}[kind]
+    B = max(1, min(args.batch, F))
+    slots = 2
+    dev_frames = [eng.empty((B, H, W, 3), torch.uint8) for _ in range(slots)]
+    dev_spans = [eng.empty((B, K, W), torch.int32) for _ in range(slots)]
+    frame_bytes = W * H * 3
+    stft_bytes = 4 * track.channels * min(track.hop, 1024) + 4 * 1025 + 8
+
+    def step(ev_fill=None, ev_stft=None):
+        if ev_stft is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        an = eng.analyze(track, want_samples=(kind == "waveform_linear"))
+        if ev_stft is not None:
+            e1.record()
+            ev_stft.append((e0, e1, F))
+        sc = eng.scan(an)
+        done, i = 0, 0
+        while done < F:
+            n = min(B, F - done)
+            s = i % slots
+            spans, _ = eng.spans(kind, an, sc, W, H, done, n, out=dev_spans[s][:n])
+            if ev_fill is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            eng.fill(spans, K, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n])
+            if ev_fill is not None:
+                e1.record()
+                ev_fill.append((e0, e1, n))
+            done += n
+            i += 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    ev_fill, ev_stft = [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(ev_fill, ev_stft)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    def kernel_stats(events, bytes_per_frame):
+        ms = sum(a.elapsed_time(b) for a, b, _ in events)
+        frames = sum(n for _, _, n in events)
+        launches = len(events)
+        if launches == 0 or ms <= 0:
+            return None
+        gbs = frames * bytes_per_frame / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(ms / launches, 4), "frames_per_launch": round(frames / launches, 1),
+                "algorithmic_bytes_per_frame": bytes_per_frame}
+
+    roof = kernel_stats(ev_fill, frame_bytes)
+    roof_stft = kernel_stats(ev_stft, stft_bytes)
+    if roof is not None:
+        roof["kernel"] = f"raster_fill_kernel<{K}>"
+    if roof_stft is not None:
+        roof_stft["kernel"] = f"stft_frames_kernel<{track.channels}>"
+    try:                                               # per-launch HBM bytes from separate --pmc passes, if collected
+        with open(args.traffic_json) as fh:
+            tj = json.load(fh)
+        key = f"{W}x{H}x{B}"
+        if roof is not None and tj.get("raster_fill", {}).get("config") == key:
+            roof["traffic"] = tj["raster_fill"]["hbm_bytes_per_launch"]
+        if roof_stft is not None and tj.get("stft", {}).get("frames") == F:
+            roof_stft["traffic"] = tj["stft"]["hbm_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+
+    pcie_fps = None
+    if args.pcie_frames > 0 and rank == 0:
+        nf = min(F, args.pcie_frames)
+        pipe = FramePipeline(eng, track, args.mode, W, H, frame_begin=0, frame_end=nf, batch_frames=min(64, nf),
+                             slots=3)
+        pipe.analyse()
+        sink = NullSink()
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        pipe.run(sink)
+        pcie_fps = nf / (time.perf_counter() - t1)
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        value = world * F * args.steps / dt
+        out = {
+            "metric": "exported frames/sec (whole node) 4K60 spectrum mode; STFT GB/s",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64 FFT / f32 magnitudes / u8 RGB24",
+            "data": "synthetic",
+            "config": {"workload": f"configs[4] unit: {args.seconds:.0f} s {sr} Hz stereo pink-noise track per GPU, "
+                                   f"{args.mode} {W}x{H}@{fps}, {F} frames per GPU per step, frames stay in HBM",
+                       "frames_per_gpu": F, "batch_frames": B, "parallelism": f"time/track shards x{world}"},
+            "stft_gbs": roof_stft["achieved"] if roof_stft else None,
+            "roofline": roof, "roofline_stft": roof_stft, "cpu_baseline": cpu,
+            "pcie_inclusive_fps": round(pcie_fps, 1) if pcie_fps else None,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,9 @@ extern "C" int aur_create(int device, aur_ctx** out) {
     }
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
+    if (const char* e = getenv("AUR_FILL_ROWS")) ctx->fill_rows = atoi(e);
+    if (const char* e = getenv("AUR_FILL_NT")) ctx->fill_nt = atoi(e);
+    if (const char* e = getenv("AUR_STFT_FPW")) ctx->stft_fpw = atoi(e);
     double h_tw[AUR_TW_DOUBLES];
     build_tables(ctx->h_window, h_tw);
     hipError_t e = hipMalloc((void**)&ctx->d_window, sizeof(float) * AUR_FFT_SIZE);

@@ -25,6 +25,10 @@ struct aur_ctx {
     double* d_twid;        // AUR_TW_DOUBLES doubles
     float h_window[AUR_FFT_SIZE];
     int num_cus;
+    // tuning knobs, read once from the environment in aur_create (0 = built-in default)
+    int fill_rows;         // AUR_FILL_ROWS: rows per wave task of the fill kernel
+    int fill_nt;           // AUR_FILL_NT=1: non-temporal frame stores
+    int stft_fpw;          // AUR_STFT_FPW: frames per wave of the STFT kernel
 };
 
 void aur_set_error(const char* fmt, ...);

@@ -283,6 +283,90 @@ __global__ __launch_bounds__(256) void raster_fill_kernel(const uint32_t* __rest
     }
 }
 
+// Fast path (W % 16 == 0, 16-byte aligned frames: every standard video size): the frame is walked as uint4
+// (16-byte) columns.  16 bytes hold 5 1/3 RGB pixels, so uint4 column i of a row starts at pixel (16 i) / 3 with
+// byte phase i % 3 and touches 6 pixel columns.  One wave owns 64 consecutive uint4 columns x kRowsPerTask rows:
+// every store instruction writes 1 KB of contiguous, line-aligned bytes (full 128-byte lines, no partial-line
+// traffic).  A lane keeps the spans of its 6 pixel columns in registers; rows outside the union of those spans
+// (almost all of a frame) store a precomputed background pattern.
+constexpr int kRowsPerTask = 16;
+
+__device__ __forceinline__ uint4 pack_rgb16(const uint32_t (&P)[6], int ph) {
+    const uint32_t s0 = P[0] | (P[1] << 24);
+    const uint32_t s1 = (P[1] >> 8) | (P[2] << 16);
+    const uint32_t s2 = (P[2] >> 16) | (P[3] << 8);
+    const uint32_t s3 = P[4] | (P[5] << 24);
+    const uint32_t s4 = P[5] >> 8;
+    uint4 o;
+    o.x = __builtin_amdgcn_alignbyte(s1, s0, ph);
+    o.y = __builtin_amdgcn_alignbyte(s2, s1, ph);
+    o.z = __builtin_amdgcn_alignbyte(s3, s2, ph);
+    o.w = __builtin_amdgcn_alignbyte(s4, s3, ph);
+    return o;
+}
+
+template <int K, bool kNT>
+__global__ __launch_bounds__(256) void raster_fill16_kernel(const uint32_t* __restrict__ spans,
+                                                            const uint32_t* __restrict__ pen_rgb, int W, int H,
+                                                            int nu4, int nchunks, int rows_per_task,
+                                                            uint4* __restrict__ frames) {
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int chunk = task % nchunks, tile = task / nchunks;
+    const int row0 = tile * rows_per_task;
+    const int i = chunk * 64 + lane;
+    if (row0 >= H || i >= nu4) return;
+    const int row1 = (row0 + rows_per_task < H) ? row0 + rows_per_task : H;
+    const int c0 = (16 * i) / 3;
+    const int ph = i % 3;                               // (16 i) mod 3
+    const uint32_t pen = pen_rgb[f] & 0x00ffffffu;
+    const uint32_t* sp = spans + (long)f * K * W;
+
+    uint32_t lo[K][6], len[K][6];
+    uint32_t umin = 0xffffu, umax = 0u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const uint32_t v = sp[(long)k * W + c0 + c];
+            const uint32_t a = v & 0xffffu, b = v >> 16;
+            lo[k][c] = a;
+            len[k][c] = b - a;                          // 0 for an empty span
+            if (b > a) {
+                umin = a < umin ? a : umin;
+                umax = b > umax ? b : umax;
+            }
+        }
+    }
+    const uint32_t ulen = umax > umin ? umax - umin : 0u;
+    const uint32_t Pbg[6] = {kBg24, kBg24, kBg24, kBg24, kBg24, kBg24};
+    const uint4 bgv = pack_rgb16(Pbg, ph);
+    uint4* dst = frames + ((long)f * H + row0) * (long)nu4 + i;
+    for (int row = row0; row < row1; ++row) {
+        uint4 o = bgv;
+        if (((uint32_t)row - umin) < ulen) {
+            uint32_t P[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                bool lit = false;
+#pragma unroll
+                for (int k = 0; k < K; ++k) lit |= ((uint32_t)row - lo[k][c]) < len[k][c];
+                P[c] = lit ? pen : kBg24;
+            }
+            o = pack_rgb16(P, ph);
+        }
+        if (kNT) {
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 ov = {o.x, o.y, o.z, o.w};
+            __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(dst));
+        } else {
+            *dst = o;
+        }
+        dst += nu4;
+    }
+}
+
 int check_raster_dims(const char* who, int n_frames, int W, int H) {
     AUR_REQUIRE(n_frames >= 0, "%s: n_frames %d < 0", who, n_frames);
     AUR_REQUIRE(W >= 160 && W <= 16384 && H >= 16 && H <= 16384, "%s: frame size %dx%d outside [160..16384]x[16..16384]",
@@ -346,20 +430,34 @@ extern "C" int aur_raster_spans(aur_ctx* ctx, const uint32_t* d_spans, int K, co
     AUR_REQUIRE(W % 4 == 0, "aur_raster_spans: width %d must be a multiple of 4", W);
     AUR_REQUIRE(((uintptr_t)d_frames & 3u) == 0 && ((uintptr_t)d_spans & 15u) == 0 && ((uintptr_t)d_pen_rgb & 3u) == 0,
                 "aur_raster_spans: misaligned device pointer");
-    const dim3 grid((unsigned)((W / 4 + 255) / 256), (unsigned)((H + kRowsPerBlock - 1) / kRowsPerBlock),
-                    (unsigned)n_frames);
     const uint32_t* pen = reinterpret_cast<const uint32_t*>(d_pen_rgb);
     hipStream_t st = (hipStream_t)stream;
-    switch (K) {
-        case 2:
+    if (K != 2 && K != 5) {
+        aur_set_error("aur_raster_spans: K=%d unsupported (2 or 5)", K);
+        return AUR_EINVAL;
+    }
+    if (W % 16 == 0 && ((uintptr_t)d_frames & 15u) == 0) {
+        const int nu4 = W * 3 / 16, nchunks = (nu4 + 63) / 64;
+        const int rpt = ctx->fill_rows > 0 ? ctx->fill_rows : kRowsPerTask;
+        const int ntiles = (H + rpt - 1) / rpt;
+        const dim3 grid((unsigned)((nchunks * ntiles + 3) / 4), (unsigned)n_frames);
+        uint4* out = reinterpret_cast<uint4*>(d_frames);
+#define AUR_LAUNCH_FILL16(KK, NT)                                                                              \
+    hipLaunchKernelGGL((raster_fill16_kernel<KK, NT>), grid, dim3(256), 0, st, d_spans, pen, W, H, nu4, nchunks, \
+                       rpt, out)
+        if (K == 2) {
+            if (ctx->fill_nt) AUR_LAUNCH_FILL16(2, true); else AUR_LAUNCH_FILL16(2, false);
+        } else {
+            if (ctx->fill_nt) AUR_LAUNCH_FILL16(5, true); else AUR_LAUNCH_FILL16(5, false);
+        }
+#undef AUR_LAUNCH_FILL16
+    } else {   // generic widths (multiples of 4): 12-byte stores
+        const dim3 grid((unsigned)((W / 4 + 255) / 256), (unsigned)((H + kRowsPerBlock - 1) / kRowsPerBlock),
+                        (unsigned)n_frames);
+        if (K == 2)
             hipLaunchKernelGGL(raster_fill_kernel<2>, grid, dim3(256), 0, st, d_spans, pen, W, H, d_frames);
-            break;
-        case 5:
+        else
             hipLaunchKernelGGL(raster_fill_kernel<5>, grid, dim3(256), 0, st, d_spans, pen, W, H, d_frames);
-            break;
-        default:
-            aur_set_error("aur_raster_spans: K=%d unsupported (2 or 5)", K);
-            return AUR_EINVAL;
     }
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;

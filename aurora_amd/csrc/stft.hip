@@ -470,6 +470,7 @@ int launch_stft(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int
     int fpw = 32;
     const long waves_wanted = (long)ctx->num_cus * 12 * 2;
     while (fpw > 4 && (long)(n_frames + fpw - 1) / fpw < waves_wanted) fpw >>= 1;
+    if (ctx->stft_fpw > 0) fpw = ctx->stft_fpw;
     const long n_waves = ((long)n_frames + fpw - 1) / fpw;
     const unsigned grid = (unsigned)((n_waves + kWavesPerWG - 1) / kWavesPerWG);
     hipLaunchKernelGGL(stft_frames_kernel<C>, dim3(grid), dim3(kWavesPerWG * 64), kLdsBytes, st, d_audio,

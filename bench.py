@@ -172,7 +172,7 @@ def main():
     roof = kernel_stats(ev_fill, frame_bytes)
     roof_stft = kernel_stats(ev_stft, stft_bytes)
     if roof is not None:
-        roof["kernel"] = f"raster_fill_kernel<{K}>"
+        roof["kernel"] = f"raster_fill16_kernel<{K}>"
     if roof_stft is not None:
         roof_stft["kernel"] = f"stft_frames_kernel<{track.channels}>"
     try:                                               # per-launch HBM bytes from separate --pmc passes, if collected

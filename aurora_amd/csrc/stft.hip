@@ -35,7 +35,8 @@ namespace {
 constexpr int kWavesPerWG = 4;
 constexpr int kXbufDoubles = 16 * 66;            // exchange buffer per wave: 16 rows of 66 doubles, 8448 B
 constexpr int kLdsWinBytes = AUR_FFT_SIZE * 4;   // float32 window
-constexpr int kLdsTw2Bytes = 4 * 16 * 16;        // W64^(r q), complex double
+constexpr int kTw2Stride = 17;                   // complex doubles per W64 row (16 + 1 pad: rows on distinct banks)
+constexpr int kLdsTw2Bytes = 4 * kTw2Stride * 16;   // W64^(r q), complex double
 constexpr int kLdsBytes = kLdsWinBytes + kLdsTw2Bytes + kWavesPerWG * kXbufDoubles * 8;
 
 struct cd {
@@ -183,7 +184,7 @@ __device__ __forceinline__ Tables stage_tables(const float* __restrict__ window,
     const float4* wsrc = reinterpret_cast<const float4*>(window);
     for (int i = threadIdx.x; i < AUR_FFT_SIZE / 4; i += blockDim.x) w4[i] = wsrc[i];
     double* t2 = reinterpret_cast<double*>(smem + kLdsWinBytes);
-    for (int i = threadIdx.x; i < 128; i += blockDim.x) t2[i] = twid[AUR_TW_W2 + i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) t2[2 * kTw2Stride * (i >> 5) + (i & 31)] = twid[AUR_TW_W2 + i];
     Tables t;
     t.win = reinterpret_cast<const float2*>(smem);
     t.tw2 = reinterpret_cast<const cd*>(t2);
@@ -258,7 +259,7 @@ __device__ __forceinline__ void fft_packed(const float (&prv)[16], const float (
 #pragma unroll
     for (int i = 1; i < 16; ++i) {
         const int q = (i >> 2) + 4 * (i & 3);
-        v[i] = cmul(v[i], T.tw2[hi2 * 16 + q]);
+        v[i] = cmul(v[i], T.tw2[hi2 * kTw2Stride + q]);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) xb[lo4 + 16 * ((i >> 2) + 4 * (i & 3)) + 256 * hi2] = v[i].x;
@@ -280,40 +281,58 @@ __device__ __forceinline__ void fft_packed(const float (&prv)[16], const float (
 // register of v[] that holds Z[lane + 64 j] after fft_packed
 __device__ __forceinline__ constexpr int zreg(int j) { return 4 * (j & 3) + (j >> 2); }
 
-// |X| in float32 from |X|^2 in float64: one rounding into float32, v_sqrt_f32 (1 ulp); the rare values whose
-// square leaves the float32 normal range take the float64 square root.
-__device__ __forceinline__ float mag_from_sq(double m2) {
-    const float f = (float)m2;
-    float mag = __builtin_amdgcn_sqrtf(f);
-    if (__builtin_expect((f < 1.0e-30f && m2 > 0.0) || f > 1.0e30f, 0)) mag = (float)sqrt(m2);
-    return mag;
+// |X| in float32 from |X|^2 in float64: v_sqrt_f64 (good to 2^-23 relative over the whole float64 range, so no
+// scaling and no underflow for leakage bins) rounded once to float32: within 1.5 ulp of the exact magnitude.
+__device__ __forceinline__ float mag_from_sq(double m2) { return (float)__builtin_amdgcn_sqrt(m2); }
+
+// log1p for x >= 0 in float32, a few ulp (the contract is rtol 1e-4; np.log1p is within 1 ulp):
+//   x <  0.5 : 2 atanh(s), s = x / (2 + x) <= 0.2, odd series through s^11 (truncation 3e-10 relative);
+//   x >= 0.5 : ln2 * log2(u) + c / u with u = fl(1 + x) and c = x - (u - 1) the rounding error of u.
+__device__ __forceinline__ float log1p_pos(float x) {
+    const float u = 1.0f + x;
+    const float c = x - (u - 1.0f);
+    const float big = fmaf(c, __builtin_amdgcn_rcpf(u), __builtin_amdgcn_logf(u) * 0.693147180559945309f);
+    const float s = x * __builtin_amdgcn_rcpf(2.0f + x);
+    const float s2 = s * s;
+    float p = fmaf(s2, 1.0f / 11.0f, 1.0f / 9.0f);
+    p = fmaf(s2, p, 1.0f / 7.0f);
+    p = fmaf(s2, p, 1.0f / 5.0f);
+    p = fmaf(s2, p, 1.0f / 3.0f);
+    const float s_2 = s + s;
+    const float small = fmaf(s_2 * s2, p, s_2);
+    return (x < 0.5f) ? small : big;
 }
 
-// W32^j = exp(-2 pi i j / 32), j < 16
-__device__ constexpr double kW32re[16] = {
-    1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
-    0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785,
-    0.0, -0.19509032201612826785, -0.38268343236508977173, -0.55557023301960222474,
-    -0.70710678118654752440, -0.83146961230254523708, -0.92387953251128675613, -0.98078528040323044913};
-__device__ constexpr double kW32im[16] = {
-    -0.0, -0.19509032201612826785, -0.38268343236508977173, -0.55557023301960222474,
-    -0.70710678118654752440, -0.83146961230254523708, -0.92387953251128675613, -0.98078528040323044913,
-    -1.0, -0.98078528040323044913, -0.92387953251128675613, -0.83146961230254523708,
-    -0.70710678118654752440, -0.55557023301960222474, -0.38268343236508977173, -0.19509032201612826785};
+// W32^j = exp(-2 pi i j / 32), j < 8
+__device__ constexpr double kW32re[8] = {1.0, 0.98078528040323044913, 0.92387953251128675613,
+                                         0.83146961230254523708, 0.70710678118654752440, 0.55557023301960222474,
+                                         0.38268343236508977173, 0.19509032201612826785};
+__device__ constexpr double kW32im[8] = {-0.0, -0.19509032201612826785, -0.38268343236508977173,
+                                         -0.55557023301960222474, -0.70710678118654752440, -0.83146961230254523708,
+                                         -0.92387953251128675613, -0.98078528040323044913};
 
-// Real-FFT unpack -> |X| -> flux partial vs pmag (updated in place) -> log1p.
-// Bins k = lane + 64 j; the partner Z[1024 - k] sits in lane (64 - lane) % 64 and is fetched with ds_bpermute.
-// lg[j] = log1p|X[lane + 64 j]|, lg_ny = log1p|X[1024]| (valid in lane 0).  Returns this lane's flux partial.
-__device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, bool emit,
-                                            float (&pmag)[16], float& pmag_ny, float (&lg)[16], float& lg_ny) {
+// Per-lane spectrum state: lane l owns the bin pairs (kA, kB) = (l + 64 j, 1024 - l - 64 j), j < 8, which tile
+// bins 0..1024 except bin 512; lane 0 also owns bin 512 ("mid").
+struct Mags {
+    float a[8], b[8], mid;
+};
+
+// Real-FFT unpack -> |X| -> flux partial vs pm (updated in place) -> log1p.
+// X[kA] = E + T and X[kB] = conj(E - T) share E = (Z[kA] + conj Z[1024 - kA]) / 2 and
+// T = W2048^kA * (-i) (Z[kA] - conj Z[1024 - kA]) / 2, so a lane computes both bins of a pair from one product.
+// The partner Z[1024 - kA] sits in lane (64 - l) % 64, register j' = 15 - j, and is fetched with ds_bpermute; in
+// lane 0 it is the lane's own register 16 - j (bin 0 pairs with itself: X[0], X[1024] = Re Z[0] +- Im Z[0]).
+// Returns this lane's flux partial; lg = log1p|X| when emit.
+__device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, bool emit, Mags& pm,
+                                            Mags& lg) {
     const int src_lane4 = ((64 - lane) & 63) * 4;
     const cd wuh = opaque(T.wuh);
     float fl = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < 8; ++j) {
         double c = bperm_f64(src_lane4, v[zreg(15 - j)].x);
         double d = bperm_f64(src_lane4, v[zreg(15 - j)].y);
-        if (lane == 0) {   // lane 0: partner of bin 64 j is bin 1024 - 64 j = own register 16 - j (bin 0: itself)
+        if (lane == 0) {
             const cd own = (j == 0) ? v[zreg(0)] : v[zreg(16 - j)];
             c = own.x;
             d = own.y;
@@ -321,24 +340,57 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
         const double a = v[zreg(j)].x, b = v[zreg(j)].y;
         // th = 0.5 * W2048^(lane + 64 j) = wuh * W32^j
         const cd th = (j == 0) ? wuh : cmul(wuh, cd{kW32re[j], kW32im[j]});
-        const double ex = a + c, ey = b - d;     // 2E = Z[k] + conj(Z[N-k])
+        const double ex = a + c, ey = b - d;     // 2E
         const double ox = b + d, oy = c - a;     // 2O = -i (Z[k] - conj(Z[N-k]))
-        const double re = fma(0.5, ex, fma(th.x, ox, -(th.y * oy)));
-        const double im = fma(0.5, ey, fma(th.x, oy, th.y * ox));
-        const float mag = mag_from_sq(fma(re, re, im * im));
-        fl += fmaxf(0.0f, mag - pmag[j]);
-        pmag[j] = mag;
-        if (emit) lg[j] = log1pf(mag);
-    }
-    {   // bin 1024 = Re Z[0] - Im Z[0] (lane 0)
-        const float mag = (float)fabs(v[zreg(0)].x - v[zreg(0)].y);
-        if (lane == 0) {
-            fl += fmaxf(0.0f, mag - pmag_ny);
-            pmag_ny = mag;
+        const double tx = fma(th.x, ox, -(th.y * oy));
+        const double ty = fma(th.x, oy, th.y * ox);
+        const double ar = fma(0.5, ex, tx), ai = fma(0.5, ey, ty);
+        const double br = fma(0.5, ex, -tx), bi = fma(0.5, ey, -ty);
+        const float ma = mag_from_sq(fma(ar, ar, ai * ai));
+        const float mb = mag_from_sq(fma(br, br, bi * bi));
+        fl += fmaxf(0.0f, ma - pm.a[j]);
+        fl += fmaxf(0.0f, mb - pm.b[j]);
+        pm.a[j] = ma;
+        pm.b[j] = mb;
+        if (emit) {
+            lg.a[j] = log1p_pos(ma);
+            lg.b[j] = log1p_pos(mb);
         }
-        if (emit) lg_ny = log1pf(mag);
+    }
+    {   // bin 512 (lane 0): X[512] = conj(Z[512])
+        const cd z8 = v[zreg(8)];
+        const float mm = mag_from_sq(fma(z8.x, z8.x, z8.y * z8.y));
+        if (lane == 0) {
+            fl += fmaxf(0.0f, mm - pm.mid);
+            pm.mid = mm;
+        }
+        if (emit) lg.mid = log1p_pos(mm);
     }
     return fl;
+}
+
+__device__ __forceinline__ void mags_zero(Mags& m) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m.a[j] = m.b[j] = 0.0f;
+    m.mid = 0.0f;
+}
+
+__device__ __forceinline__ void mags_load(Mags& m, const float* __restrict__ src, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        m.a[j] = src[lane + 64 * j];
+        m.b[j] = src[1024 - lane - 64 * j];
+    }
+    m.mid = src[512];
+}
+
+__device__ __forceinline__ void mags_store(const Mags& m, float* __restrict__ dst, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        dst[lane + 64 * j] = m.a[j];
+        dst[1024 - lane - 64 * j] = m.b[j];
+    }
+    if (lane == 0) dst[512] = m.mid;
 }
 
 template <int C>
@@ -361,14 +413,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void stft_frames_kernel(
     if (c0 >= frame_end) return;   // no block-level barrier below this point
     const long cend = (c0 + frames_per_wave < frame_end) ? c0 + frames_per_wave : frame_end;
 
-    float prv[16], cur[16], pmag[16], lg[16];
-    float pmag_ny = 0.0f, lg_ny = 0.0f;   // bin 1024 (lane 0 only)
+    float prv[16], cur[16];
+    Mags pmag, lg;                        // Analyzer.prev_mag of this wave's bins; log1p|X| of the current frame
     cd v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        pmag[i] = 0.0f;
-        lg[i] = 0.0f;
-    }
+    mags_zero(pmag);
+    mags_zero(lg);
     const bool want_log = (logspec != nullptr) || (bandmax != nullptr);
 
     // Analyzer.buffer starts at zero (analysis.py:14); a chunk that starts inside the track first replays frame
@@ -394,20 +443,17 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void stft_frames_kernel(
 
         fft_packed(prv, cur, lane, T, xb, v);
         // analysis-only pre-pass (carried smoothing state) and the halo frame: no log1p, no spectrum store
-        float fl = unpack_mag(v, lane, T, want_log && store, pmag, pmag_ny, lg, lg_ny);
+        float fl = unpack_mag(v, lane, T, want_log && store, pmag, lg);
         if (store) {
             if (logspec != nullptr) {
-                float* out = logspec + fo * AUR_NBINS;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) out[lane + 64 * j] = lg[j];
-                if (lane == 0) out[1024] = lg_ny;
+                mags_store(lg, logspec + fo * AUR_NBINS, lane);
             }
             fl = wave_sum_xor(fl);
             if (lane == 0) flux_sum[fo] = fl;
             if (bandmax != nullptr) {
                 // bins < 80: j = 0 (all lanes) and j = 1 (lanes < 16); bins < 50: j = 0, lanes < 50.  log1p >= 0.
-                float bm80 = fmaxf(lg[0], (lane < 16) ? lg[1] : 0.0f);
-                float bm50 = (lane < 50) ? lg[0] : 0.0f;
+                float bm80 = fmaxf(lg.a[0], (lane < 16) ? lg.a[1] : 0.0f);
+                float bm50 = (lane < 50) ? lg.a[0] : 0.0f;
                 bm80 = wave_max_xor(bm80);
                 bm50 = wave_max_xor(bm50);
                 if (lane == 0) {
@@ -432,8 +478,8 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
     const int lane = threadIdx.x;
     const Tables T = stage_tables(window, twid, smem, lane);
     double* xb = reinterpret_cast<double*>(smem + kLdsWinBytes + kLdsTw2Bytes);
-    float prv[16], cur[16], pmag[16], lg[16];
-    float pmag_ny = 0.0f, lg_ny = 0.0f;
+    float prv[16], cur[16];
+    Mags pmag, lg;
     cd v[16];
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
@@ -444,20 +490,11 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
         cur[2 * jj] = b.x;
         cur[2 * jj + 1] = b.y;
     }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) pmag[j] = prev_mag[lane + 64 * j];
-    if (lane == 0) pmag_ny = prev_mag[1024];
+    mags_load(pmag, prev_mag, lane);
     fft_packed(prv, cur, lane, T, xb, v);
-    float fl = unpack_mag(v, lane, T, true, pmag, pmag_ny, lg, lg_ny);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        logspec[lane + 64 * j] = lg[j];
-        prev_mag[lane + 64 * j] = pmag[j];
-    }
-    if (lane == 0) {
-        logspec[1024] = lg_ny;
-        prev_mag[1024] = pmag_ny;
-    }
+    float fl = unpack_mag(v, lane, T, true, pmag, lg);
+    mags_store(lg, logspec, lane);
+    mags_store(pmag, prev_mag, lane);
     fl = wave_sum_xor(fl);
     if (lane == 0) flux_sum[0] = fl;
 }

@@ -1,0 +1,19 @@
+#!/bin/bash
+# rocprofv3 counter passes for bench.py (GPU box).  One --pmc pass per run (no trace domains combined).
+# Usage: bash tools/pmc_passes.sh <tag>      -> gpurun_out/pmc_<tag>/{fetch,write,sq}/..._counter_collection.csv
+set -e
+tag=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+BENCH="bench.py --steps 1 --warmup 0 --cpu-frames 0 --pcie-frames 0"
+out=gpurun_out/pmc_$tag
+mkdir -p $out
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o p -- python3 $BENCH > $out/fetch.log 2>&1
+echo "fetch pass done"
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o p -- python3 $BENCH > $out/write.log 2>&1
+echo "write pass done"
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY --output-format csv -d $out/sq -o p -- python3 $BENCH > $out/sq.log 2>&1
+echo "sq pass done"
+python3 tools/pmc_summarize.py $out > $out/summary.txt
+cat $out/summary.txt
+# keep only the aggregated rows: the raw per-dispatch CSVs are large
+find $out -name "*_counter_collection.csv" -size +8M -delete

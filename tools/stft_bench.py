@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused STFT kernel alone (GPU box): ms per launch, frames/s, algorithmic GB/s.
+
+    python tools/stft_bench.py [--seconds 3600] [--reps 10] [--check]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=3600.0)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--check", action="store_true", help="compare 300 frames with the numpy oracle")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from aurora_amd import synth
+    from aurora_amd.engine import get_engine
+
+    eng = get_engine(0)
+    sr, fps = 48000, 60
+    audio = synth.pink_device(int(args.seconds * sr), 2, 1234, eng.device)
+    track = eng.make_track(audio, sr, fps)
+    F = track.total_frames
+    for _ in range(2):
+        an = eng.analyze(track)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        an = eng.analyze(track)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.reps
+    bytes_per_frame = 4 * 2 * min(track.hop, 1024) + 4 * 1025 + 8
+    gbs = F * bytes_per_frame / (ms * 1e-3) / 1e9
+    print(f"stft: {F} frames  {ms:.4f} ms/launch  {F / ms * 1e3 / 1e6:.1f} Mframes/s  {gbs:.1f} GB/s "
+          f"({gbs / 8000 * 100:.1f}% of 8 TB/s)")
+    if args.check:
+        from oracle import analysis_ref as A
+        n = 300
+        host = audio[: n * 800 + 4000].cpu().numpy()
+        ref = A.analyze_track(host, sr, fps)
+        m = min(n, ref["logspec"].shape[0]) - 8
+        got = an.logspec[:m].cpu().numpy().astype(np.float64)
+        want = ref["logspec"][:m].astype(np.float64)
+        rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-30)
+        print(f"check vs oracle over {m} frames: max rel err {rel.max():.3e}, max abs err {np.abs(got - want).max():.3e}, "
+              f"min |want| {want.min():.3e}")
+
+
+if __name__ == "__main__":
+    main()

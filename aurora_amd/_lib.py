@@ -11,7 +11,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaurora_hip.so")
+# AURORA_HIP_LIB selects another build of the same ABI (kernel-tuning experiments); default is the in-tree library
+LIB_PATH = os.environ.get("AURORA_HIP_LIB") or os.path.join(_HERE, "libaurora_hip.so")
 
 ABI_VERSION = 1
 

@@ -32,6 +32,9 @@
 
 namespace {
 
+#ifndef AUR_STFT_WAVES_PER_SIMD
+#define AUR_STFT_WAVES_PER_SIMD 2      // register budget of the frame kernel: 512 / this VGPRs per lane
+#endif
 constexpr int kWavesPerWG = 4;
 constexpr int kXbufDoubles = 16 * 66;            // exchange buffer per wave: 16 rows of 66 doubles, 8448 B
 constexpr int kLdsWinBytes = AUR_FFT_SIZE * 4;   // float32 window
@@ -95,26 +98,6 @@ __device__ __forceinline__ void dft16(cd (&v)[16]) {
     for (int c = 0; c < 4; ++c) radix4(v[4 * c + 0], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
 }
 
-// p[k] = w^k for k = 1..15 by a depth-4 product tree (p[0] is not used)
-__device__ __forceinline__ void pow_chain(cd w, cd (&p)[16]) {
-    p[0] = cd{1.0, 0.0};
-    p[1] = w;
-    p[2] = cmul(p[1], p[1]);
-    p[3] = cmul(p[2], p[1]);
-    p[4] = cmul(p[2], p[2]);
-    p[5] = cmul(p[4], p[1]);
-    p[6] = cmul(p[3], p[3]);
-    p[7] = cmul(p[4], p[3]);
-    p[8] = cmul(p[4], p[4]);
-    p[9] = cmul(p[8], p[1]);
-    p[10] = cmul(p[5], p[5]);
-    p[11] = cmul(p[8], p[3]);
-    p[12] = cmul(p[6], p[6]);
-    p[13] = cmul(p[8], p[5]);
-    p[14] = cmul(p[7], p[7]);
-    p[15] = cmul(p[8], p[7]);
-}
-
 __device__ __forceinline__ float wave_sum_xor(float v) {
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
@@ -134,37 +117,71 @@ __device__ __forceinline__ double bperm_f64(int src_lane4, double v) {
     return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
 }
 
+// 16 / 8 bytes of interleaved samples at their natural alignment (frame positions are arbitrary sample offsets)
+struct __attribute__((aligned(8))) f4a8 {
+    float x, y, z, w;
+};
+struct __attribute__((aligned(4))) f2a4 {
+    float x, y;
+};
+
 // One 1024-sample analysis block of frame `fi` (exporter.py:230-237) in the lane layout of the FFT:
 // blk[2jj], blk[2jj+1] = samples[2*lane + 128*jj], samples[2*lane + 128*jj + 1].
+// Frames whose whole 1024-sample read window lies inside the track (all but the last one or two) take a
+// branch-free path: eight unconditional 16-byte loads issued back to back, zero padding by select.
 template <int C>
 __device__ __forceinline__ void load_block(const float* __restrict__ audio, long n_samp,
                                            const long* __restrict__ pos, long fi, int hop, int lane,
                                            float (&blk)[16]) {
+    if (fi < 0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) blk[i] = 0.0f;
-    if (fi < 0) return;
+        for (int i = 0; i < 16; ++i) blk[i] = 0.0f;
+        return;
+    }
     const long p = pos[fi];
     long nv = n_samp - p;
     if (nv > hop) nv = hop;
     if (nv > AUR_BLOCK) nv = AUR_BLOCK;
     const int nvalid = (int)nv;
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-        const int s = 2 * lane + 128 * jj;
+    if (p + AUR_BLOCK <= n_samp) {           // wave-uniform
         if (C == 2) {
-            const float2* src = reinterpret_cast<const float2*>(audio + (p + s) * 2);
-            if (s + 1 < nvalid) {
-                const float2 a = src[0], b = src[1];
-                blk[2 * jj] = (a.x + a.y) * 0.5f;        // y.mean(axis=1), exporter.py:234
-                blk[2 * jj + 1] = (b.x + b.y) * 0.5f;
-            } else if (s < nvalid) {
-                const float2 a = src[0];
-                blk[2 * jj] = (a.x + a.y) * 0.5f;
+            const f4a8* src = reinterpret_cast<const f4a8*>(audio + (p + 2 * lane) * 2);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const f4a8 q = src[64 * jj];                         // (L0, R0, L1, R1) of samples s, s + 1
+                const int s = 2 * lane + 128 * jj;
+                const float m0 = (q.x + q.y) * 0.5f;                 // y.mean(axis=1), exporter.py:234
+                const float m1 = (q.z + q.w) * 0.5f;
+                blk[2 * jj] = (s < nvalid) ? m0 : 0.0f;
+                blk[2 * jj + 1] = (s + 1 < nvalid) ? m1 : 0.0f;
             }
         } else {
-            const float* src = audio + (p + s);
-            if (s < nvalid) blk[2 * jj] = src[0];
-            if (s + 1 < nvalid) blk[2 * jj + 1] = src[1];
+            const f2a4* src = reinterpret_cast<const f2a4*>(audio + (p + 2 * lane));
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const f2a4 q = src[64 * jj];
+                const int s = 2 * lane + 128 * jj;
+                blk[2 * jj] = (s < nvalid) ? q.x : 0.0f;
+                blk[2 * jj + 1] = (s + 1 < nvalid) ? q.y : 0.0f;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) blk[i] = 0.0f;
+#pragma unroll 1
+    for (int jj = 0; jj < 8; ++jj) {         // end of track: guarded scalar loads
+        const int s = 2 * lane + 128 * jj;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (s + t < nvalid) {
+                const float* src = audio + (p + s + t) * C;
+                const float m = (C == 2) ? (src[0] + src[1]) * 0.5f : src[0];
+                // blk index is a compile-time constant only under full unrolling; select instead
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k == jj) blk[2 * k + t] = m;
+            }
         }
     }
 }
@@ -232,13 +249,15 @@ __device__ __forceinline__ void fft_packed(const float (&prv)[16], const float (
     // pass 1: radix-16 over j, twiddle W1024^(l k1), transpose through LDS (rows padded to 66: conflict-free)
     dft16(v);
     {
-        // the powers are rebuilt per frame on purpose: kept across frames they would pin 60 VGPRs (opaque())
-        cd p[16];
-        pow_chain(opaque(T.w1), p);
+        // W1024^(l k1) as a running product of the per-lane base: two live complex values, rebuilt per frame
+        // (a 15-entry power table kept across frames would pin 60 VGPRs)
+        const cd w1 = opaque(T.w1);
+        cd p = w1;
 #pragma unroll
-        for (int i = 1; i < 16; ++i) {
-            const int k1 = (i >> 2) + 4 * (i & 3);
-            v[i] = cmul(v[i], p[k1]);
+        for (int k1 = 1; k1 < 16; ++k1) {
+            const int i = 4 * (k1 & 3) + (k1 >> 2);     // register that holds output k1 of dft16
+            v[i] = cmul(v[i], p);
+            if (k1 < 15) p = cmul(p, w1);
         }
     }
     const int lo4 = lane & 15, hi2 = lane >> 4;
@@ -322,9 +341,10 @@ struct Mags {
 // T = W2048^kA * (-i) (Z[kA] - conj Z[1024 - kA]) / 2, so a lane computes both bins of a pair from one product.
 // The partner Z[1024 - kA] sits in lane (64 - l) % 64, register j' = 15 - j, and is fetched with ds_bpermute; in
 // lane 0 it is the lane's own register 16 - j (bin 0 pairs with itself: X[0], X[1024] = Re Z[0] +- Im Z[0]).
-// Returns this lane's flux partial; lg = log1p|X| when emit.
+// Returns this lane's flux partial.  When emit: log1p|X| is stored to `out` (float32[1025], may be null) as soon
+// as it is known, and lg0 / lg1 receive log1p|X| of bins lane and lane + 64 (band maxima).
 __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, bool emit, Mags& pm,
-                                            Mags& lg) {
+                                            float* __restrict__ out, float& lg0, float& lg1) {
     const int src_lane4 = ((64 - lane) & 63) * 4;
     const cd wuh = opaque(T.wuh);
     float fl = 0.0f;
@@ -353,8 +373,13 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
         pm.a[j] = ma;
         pm.b[j] = mb;
         if (emit) {
-            lg.a[j] = log1p_pos(ma);
-            lg.b[j] = log1p_pos(mb);
+            const float la = log1p_pos(ma), lb = log1p_pos(mb);
+            if (j == 0) lg0 = la;
+            if (j == 1) lg1 = la;
+            if (out != nullptr) {
+                out[lane + 64 * j] = la;
+                out[1024 - lane - 64 * j] = lb;
+            }
         }
     }
     {   // bin 512 (lane 0): X[512] = conj(Z[512])
@@ -364,7 +389,7 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
             fl += fmaxf(0.0f, mm - pm.mid);
             pm.mid = mm;
         }
-        if (emit) lg.mid = log1p_pos(mm);
+        if (emit && out != nullptr && lane == 0) out[512] = log1p_pos(mm);
     }
     return fl;
 }
@@ -394,7 +419,7 @@ __device__ __forceinline__ void mags_store(const Mags& m, float* __restrict__ ds
 }
 
 template <int C>
-__global__ __launch_bounds__(kWavesPerWG * 64, 2) void stft_frames_kernel(
+__global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stft_frames_kernel(
     const float* __restrict__ audio, long n_samp, const long* __restrict__ pos, long frame_begin, int n_frames,
     int hop, int frames_per_wave, const float* __restrict__ window, const double* __restrict__ twid,
     float* __restrict__ logspec, float* __restrict__ flux_sum, float* __restrict__ meanabs,
@@ -414,10 +439,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void stft_frames_kernel(
     const long cend = (c0 + frames_per_wave < frame_end) ? c0 + frames_per_wave : frame_end;
 
     float prv[16], cur[16];
-    Mags pmag, lg;                        // Analyzer.prev_mag of this wave's bins; log1p|X| of the current frame
+    Mags pmag;                            // Analyzer.prev_mag of this wave's bins
     cd v[16];
     mags_zero(pmag);
-    mags_zero(lg);
     const bool want_log = (logspec != nullptr) || (bandmax != nullptr);
 
     // Analyzer.buffer starts at zero (analysis.py:14); a chunk that starts inside the track first replays frame
@@ -443,17 +467,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64, 2) void stft_frames_kernel(
 
         fft_packed(prv, cur, lane, T, xb, v);
         // analysis-only pre-pass (carried smoothing state) and the halo frame: no log1p, no spectrum store
-        float fl = unpack_mag(v, lane, T, want_log && store, pmag, lg);
+        float lg0 = 0.0f, lg1 = 0.0f;
+        float fl = unpack_mag(v, lane, T, want_log && store, pmag,
+                              (logspec != nullptr) ? logspec + fo * AUR_NBINS : nullptr, lg0, lg1);
         if (store) {
-            if (logspec != nullptr) {
-                mags_store(lg, logspec + fo * AUR_NBINS, lane);
-            }
             fl = wave_sum_xor(fl);
             if (lane == 0) flux_sum[fo] = fl;
             if (bandmax != nullptr) {
                 // bins < 80: j = 0 (all lanes) and j = 1 (lanes < 16); bins < 50: j = 0, lanes < 50.  log1p >= 0.
-                float bm80 = fmaxf(lg.a[0], (lane < 16) ? lg.a[1] : 0.0f);
-                float bm50 = (lane < 50) ? lg.a[0] : 0.0f;
+                float bm80 = fmaxf(lg0, (lane < 16) ? lg1 : 0.0f);
+                float bm50 = (lane < 50) ? lg0 : 0.0f;
                 bm80 = wave_max_xor(bm80);
                 bm50 = wave_max_xor(bm50);
                 if (lane == 0) {
@@ -479,7 +502,7 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
     const Tables T = stage_tables(window, twid, smem, lane);
     double* xb = reinterpret_cast<double*>(smem + kLdsWinBytes + kLdsTw2Bytes);
     float prv[16], cur[16];
-    Mags pmag, lg;
+    Mags pmag;
     cd v[16];
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
@@ -492,8 +515,8 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
     }
     mags_load(pmag, prev_mag, lane);
     fft_packed(prv, cur, lane, T, xb, v);
-    float fl = unpack_mag(v, lane, T, true, pmag, lg);
-    mags_store(lg, logspec, lane);
+    float lg0, lg1;
+    float fl = unpack_mag(v, lane, T, true, pmag, logspec, lg0, lg1);
     mags_store(pmag, prev_mag, lane);
     fl = wave_sum_xor(fl);
     if (lane == 0) flux_sum[0] = fl;

@@ -233,7 +233,11 @@ __device__ __forceinline__ float block_meanabs(const float (&cur)[16], int lane,
 // In: prv/cur[2jj], [2jj+1] = block samples 2*lane + 128*jj, +1.
 // Out: Z[lane + 64 j] is left in v[4 * (j & 3) + (j >> 2)]  (see zreg()).
 __device__ __forceinline__ void fft_packed(const float (&prv)[16], const float (&cur)[16], int lane,
-                                           const Tables& T, double* xb, cd (&v)[16]) {
+                                           const Tables& T, double* xb_, cd (&v)[16]) {
+    // volatile: keeps one ds_read_b64 / ds_write_b64 per element.  Merged into ds_read2_b64 / ds_write2_b64 the
+    // accesses fall back to 32-bank addressing (half the LDS rate) and the padded rows conflict two ways.
+    typedef __attribute__((address_space(3))) volatile double lds_vdouble;
+    lds_vdouble* xb = (lds_vdouble*)xb_;
     // window in float32 exactly as the reference (buffer * window, analysis.py:25), then widen and pack:
     // z[l + 64 j] = (x[2n] w[2n], x[2n+1] w[2n+1])
 #pragma unroll
@@ -304,22 +308,14 @@ __device__ __forceinline__ constexpr int zreg(int j) { return 4 * (j & 3) + (j >
 // scaling and no underflow for leakage bins) rounded once to float32: within 1.5 ulp of the exact magnitude.
 __device__ __forceinline__ float mag_from_sq(double m2) { return (float)__builtin_amdgcn_sqrt(m2); }
 
-// log1p for x >= 0 in float32, a few ulp (the contract is rtol 1e-4; np.log1p is within 1 ulp):
-//   x <  0.5 : 2 atanh(s), s = x / (2 + x) <= 0.2, odd series through s^11 (truncation 3e-10 relative);
-//   x >= 0.5 : ln2 * log2(u) + c / u with u = fl(1 + x) and c = x - (u - 1) the rounding error of u.
+// log1p for x >= 0 in float32 (the contract is rtol 1e-4; np.log1p is within 1 ulp; this is within ~3 ulp):
+// ln2 * log2(u) + c / u with u = fl(1 + x) and c = x - (u - 1) the rounding error of u.  v_log_f32 is
+// relatively accurate next to 1 (measured over the whole range by tests/test_gpu_parity.py::test_log1p_probe),
+// and for u == 1 the result is c = x exactly.
 __device__ __forceinline__ float log1p_pos(float x) {
     const float u = 1.0f + x;
     const float c = x - (u - 1.0f);
-    const float big = fmaf(c, __builtin_amdgcn_rcpf(u), __builtin_amdgcn_logf(u) * 0.693147180559945309f);
-    const float s = x * __builtin_amdgcn_rcpf(2.0f + x);
-    const float s2 = s * s;
-    float p = fmaf(s2, 1.0f / 11.0f, 1.0f / 9.0f);
-    p = fmaf(s2, p, 1.0f / 7.0f);
-    p = fmaf(s2, p, 1.0f / 5.0f);
-    p = fmaf(s2, p, 1.0f / 3.0f);
-    const float s_2 = s + s;
-    const float small = fmaf(s_2 * s2, p, s_2);
-    return (x < 0.5f) ? small : big;
+    return fmaf(c, __builtin_amdgcn_rcpf(u), __builtin_amdgcn_logf(u) * 0.693147180559945309f);
 }
 
 // W32^j = exp(-2 pi i j / 32), j < 8
@@ -522,6 +518,12 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
     if (lane == 0) flux_sum[0] = fl;
 }
 
+__global__ __launch_bounds__(256) void log1p_probe_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = log1p_pos(x[i]);
+}
+
 template <int C>
 int launch_stft(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int64_t* d_pos, int64_t frame_begin,
                 int n_frames, int hop, float* d_logspec, float* d_flux_sum, float* d_meanabs, float* d_samples,
@@ -575,6 +577,18 @@ extern "C" int aur_stft_buffer(aur_ctx* ctx, const float* d_buffer, float* d_pre
     AUR_REQUIRE(((uintptr_t)d_buffer & 7u) == 0, "aur_stft_buffer: d_buffer must be 8-byte aligned");
     hipLaunchKernelGGL(stft_buffer_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_buffer, d_prev_mag,
                        ctx->d_window, ctx->d_twid, d_logspec, d_flux_sum);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_log1p_f32(aur_ctx* ctx, const float* d_x, float* d_y, int64_t n, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n >= 0 && n <= (int64_t)1 << 31, "aur_log1p_f32: n %lld out of range", (long long)n);
+    if (n == 0) return AUR_OK;
+    AUR_REQUIRE(d_x && d_y, "aur_log1p_f32: null device pointer");
+    hipLaunchKernelGGL(log1p_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x,
+                       d_y, (long)n);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

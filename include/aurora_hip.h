@@ -98,6 +98,10 @@ int aur_stft_frames(aur_ctx* ctx,
 int aur_stft_buffer(aur_ctx* ctx, const float* d_buffer, float* d_prev_mag, float* d_logspec,
                     float* d_flux_sum, void* stream);
 
+/* The kernels' log1p (replaces np.log1p at audio/analysis.py:33 for magnitudes x >= 0) applied element-wise:
+ * d_y[i] = log1p(d_x[i]).  Exposed so the accuracy of the device routine can be tested over its whole range. */
+int aur_log1p_f32(aur_ctx* ctx, const float* d_x, float* d_y, int64_t n, void* stream);
+
 /* ---- smoothing scan over frames --------------------------------------------------------------- */
 
 typedef struct aur_scan_params {

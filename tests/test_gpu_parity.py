@@ -35,6 +35,28 @@ def test_window_bit_exact(eng):
     assert np.array_equal(eng.ctx.window(), get_window('hann', 2048, fftbins=True).astype(np.float32))
 
 
+def test_log1p_probe(eng):
+    """Device log1p (analysis.py:33) over 60 decades + every float32 in a band next to 0.5 and next to 2^-24."""
+    import ctypes as C
+    import torch
+    x = np.concatenate([
+        np.logspace(-30, 7, 2_000_001).astype(np.float32),
+        np.array([0.0, 1e-45, 1.17549435e-38, 5.9604645e-8, 1.1920929e-7, 0.5, 1.0, 3.4e38], dtype=np.float32),
+        np.arange(0x3EFFF000, 0x3F001000, dtype=np.uint32).view(np.float32),     # around 0.5
+        np.arange(0x33000000, 0x34800000, 977, dtype=np.uint32).view(np.float32),   # 2^-25 .. 2^-22: u = 1 + x rounds
+    ])
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.empty_like(dx)
+    rc = eng.lib.aur_log1p_f32(eng.ctx.handle, C.c_void_p(dx.data_ptr()), C.c_void_p(dy.data_ptr()), x.size, eng.stream())
+    assert rc == 0
+    got = dy.cpu().numpy().astype(np.float64)
+    want = np.log1p(x.astype(np.float64))
+    rel = np.abs(got - want) / np.maximum(want, 1e-300)
+    rel[want == 0] = np.abs(got[want == 0])
+    print(f"log1p probe: max rel err {rel.max():.3e} at x={x[rel.argmax()]:.6e}")
+    assert rel.max() <= 1e-6          # ~8 ulp; the contract on spectra is rtol 1e-4
+
+
 @pytest.mark.parametrize("name", golden_analysis_names())
 def test_analysis_vs_reference_fixtures(eng, name):
     from aurora_amd import _lib

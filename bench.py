@@ -95,7 +95,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
-    from aurora_amd import _lib, synth
+    from aurora_amd import _lib, sharding, synth
     from aurora_amd.engine import get_engine, mode_kind
     from aurora_amd.pipeline import FramePipeline, NullSink
 
@@ -152,10 +152,7 @@ def main():
         step(ev_fill, ev_stft)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = sharding.max_over_ranks(dt, device)
 
     def kernel_stats(events, bytes_per_frame):
         ms = sum(a.elapsed_time(b) for a, b, _ in events)

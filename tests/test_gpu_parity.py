@@ -278,3 +278,34 @@ def test_abi_rejects_bad_arguments(eng):
     assert b"channels" in lib.aur_last_error()
     hh = C.c_void_p()
     assert lib.aur_create(99, C.byref(hh)) == -1
+
+
+def test_worker_end_to_end_raw_stream(eng, tmp_path, capsys):
+    """export.worker.main: cfg JSON in, JSON-lines progress out, exit 0; the rgb24 stream equals the device render."""
+    import json
+    from scipy.io import wavfile
+    from aurora_amd import synth
+    from aurora_amd.export import worker
+    from aurora_amd.pipeline import FramePipeline
+    sr, fps, W, H = 44100, 30, 320, 192
+    audio = synth.sweep(sr + 123, sr)                                   # float32 stereo WAV, like soundfile would read
+    wav = tmp_path / "in.wav"
+    wavfile.write(str(wav), sr, audio)
+    raw = tmp_path / "out.rgb"
+    cfg = dict(audio_path=str(wav), out_path=str(tmp_path / "out.mp4"), width=W, height=H, fps=fps,
+               mode="Spectrum - Linear", color=[0.2, 0.8, 1.0], sensitivity=1.0, view_state={"hip_device": 0},
+               gpu_device="", hip_raw_out=str(raw))
+    cfgp = tmp_path / "cfg.json"
+    cfgp.write_text(json.dumps(cfg))
+    assert worker.main(["worker.py", str(cfgp)]) == 0
+    msgs = [json.loads(l) for l in capsys.readouterr().out.strip().splitlines()]
+    assert msgs[-1] == {"type": "done"} and msgs[-2] == {"type": "progress", "pct": 100}
+    assert all(m["type"] == "progress" and 0 <= m["pct"] <= 100 for m in msgs[:-1])
+    track = eng.upload_track(audio, sr, fps)
+    want = _np(FramePipeline(eng, track, "Spectrum - Linear", W, H).render_device()).tobytes()
+    assert raw.read_bytes() == want
+    # unsupported mode -> exit 1 with an error message, as the reference reports export failures (worker.py:77-79)
+    cfg["mode"] = "Spectrum - Radial"
+    cfgp.write_text(json.dumps(cfg))
+    assert worker.main(["worker.py", str(cfgp)]) == 1
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["type"] == "error"

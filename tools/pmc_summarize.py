@@ -36,6 +36,22 @@ def main(root):
     for k, counters in sorted(agg.items()):
         out[k] = {c: {"mean_per_dispatch": v[0] / v[1], "dispatches": v[1]} for c, v in sorted(counters.items())}
     print(json.dumps(out, indent=1))
+    # per-launch HBM traffic for bench.py's roofline objects: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB;
+    # on gfx950 FETCH_SIZE tallies 64 B per 128-B request on wide streaming reads, so it is doubled
+    # (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B-per-lane stores.
+    def traffic(k):
+        c = out.get(k, {})
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            return None
+        return int(round(2 * 1024 * c["FETCH_SIZE"]["mean_per_dispatch"] + 1024 * c["WRITE_SIZE"]["mean_per_dispatch"]))
+    tj = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --steps 1 --warmup 0 "
+                    "--cpu-frames 0 --pcie-frames 0` (tools/pmc_passes.sh); bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE",
+          "raster_fill": {"config": os.environ.get("AUR_PMC_FILL_CONFIG", "3840x2160x128"),
+                          "hbm_bytes_per_launch": traffic("raster_fill16_kernel")},
+          "stft": {"frames": int(os.environ.get("AUR_PMC_STFT_FRAMES", "216000")),
+                   "hbm_bytes_per_launch": traffic("stft_frames_kernel")}}
+    with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
+        json.dump(tj, fh, indent=1)
 
 
 if __name__ == "__main__":

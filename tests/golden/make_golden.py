@@ -303,7 +303,49 @@ def capture_drawlists(name, kind, n, sr, fps, sizes, frames):
     print(f"drawlists_{name}: {len(out)} arrays")
 
 
+def capture_radial_view_state(name, kind, n, sr, fps, size, frames, view_state, sensitivity=1.0):
+    """Spectrum - Radial with a non-default view_state: radial path, clip path, centre fill, feather rings."""
+    from export.exporter import QPainterOffscreenRenderer
+    audio = _track(kind, n, sr, 2)
+    path = f"mem://rv_{name}"
+    _AUDIO[path] = (audio, sr)
+    w, h = size
+    r = QPainterOffscreenRenderer(w, h, "Spectrum - Radial", (0.2, 0.8, 1.0), sensitivity, fps, path, **view_state)
+    total = int(np.ceil(r.duration * fps))
+    out = dict(audio=audio, sample_rate=sr, fps=fps, frames=np.asarray(frames), size=np.asarray(size),
+               sensitivity=sensitivity, view_state_json=np.asarray(__import__("json").dumps(view_state)))
+    keep = set(int(f) for f in frames)
+    for i in range(total):
+        s, spec = r._read_frame(i / fps)
+        img = r._view.render_frame_to_qimage(w, h, s, spec)
+        if i not in keep:
+            continue
+        calls = img.calls
+        key = f"f{i}"
+        out[key + "_path"] = _path_xy([c for c in calls if c[0] == "drawPath"][0][1])
+        out[key + "_clip"] = _path_xy([c for c in calls if c[0] == "setClipPath"][0][1])
+        fills = [c for c in calls if c[0] == "fillPath"]
+        out[key + "_fill_rgba"] = np.asarray([c[2] for c in fills], np.int64)          # centre fill, then rings
+        out[key + "_rings"] = np.asarray([_path_xy(c[1]) for c in fills[1:]], np.float64)
+        out[key + "_calls"] = np.asarray([c[0] for c in calls])
+        out[key + "_phase"] = np.float64(r._view._phase)
+    np.savez_compressed(os.path.join(HERE, f"radialvs_{name}.npz"), **out)
+    print(f"radialvs_{name}: {len(out)} arrays")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "radial_vs":      # adds the radialvs_* fixtures only
+        _install_stand_ins()
+        sys.path.insert(0, REF)
+        capture_radial_view_state("mirror_wavy", "pink", 12000, 48000, 60, (1280, 720), [0, 1, 4, 9, 14],
+                                  dict(radial_mirror=True, edge_waviness=40, feather_enabled=True,
+                                       feather_audio_enabled=True, feather_audio_amount=60,
+                                       radial_rotation_deg=17.5, radial_smooth_amount=30,
+                                       radial_waveform_smoothness=80, radial_temporal_smoothing=60))
+        capture_radial_view_state("plain_nosmooth", "sweep", 22050, 44100, 30, (1000, 562), [0, 2, 7],
+                                  dict(radial_smooth_amount=0, radial_waveform_smoothness=0,
+                                       radial_temporal_smoothing=0, edge_waviness=100), sensitivity=2.0)
+        return
     if not os.path.isdir(REF):
         raise SystemExit(f"reference not found at {REF}; fixtures can only be regenerated in the build container")
     _install_stand_ins()

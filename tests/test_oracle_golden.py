@@ -134,3 +134,66 @@ def test_pen_colour_sequence(fixture):
         assert np.array_equal(rgb[f], g[k + "_pen"]), k
         assert np.array_equal(out["samples"][f], g[k + "_samples"])
         assert np.array_equal(out["logspec"][f], g[k + "_spectrum"])
+
+
+@pytest.mark.parametrize("fixture", ["drawlists_pink_48k_60", "drawlists_sweep_44k1_30"])
+def test_radial_and_envelope_paths_match_reference(fixture):
+    """Spectrum - Radial: drawPath / setClipPath vertices of the reference, every captured frame and size.
+    The radial path carries the _radial_prev EMA, so the oracle walks all frames of the fixture's track."""
+    from oracle import radial_ref as RR
+    g = load_golden(fixture)
+    audio, sr, fps = g["audio"], int(g["sample_rate"]), int(g["fps"])
+    ref = A.analyze_track(audio, sr, fps)
+    phase = A.phase_track(ref["energy"])
+    keys = sorted(k[:-5] for k in g.files if k.startswith("radial") and k.endswith("_path"))
+    assert keys
+    sizes = sorted({k.split("_")[1] for k in keys})
+    for wh in sizes:
+        W, H = (int(v) for v in wh.split("x"))
+        tr = RR.RadialTrack()
+        for f in range(ref["samples"].shape[0]):
+            path = tr.path(ref["logspec"][f], float(ref["energy"][f]), W, H)
+            key = f"radial_{wh}_f{f}"
+            if key + "_path" not in g.files:
+                continue
+            assert np.array_equal(ref["logspec"][f], g[key + "_spectrum"])
+            assert path.shape == g[key + "_path"].shape == (721, 2)
+            assert np.array_equal(path, g[key + "_path"]), (key, float(np.max(np.abs(path - g[key + "_path"]))))
+            env = RR.envelope_path(ref["logspec"][f], float(ref["energy"][f]), float(phase[f]), W, H)
+            assert np.array_equal(env, g[key + "_clip"]), key
+            assert list(g[key + "_calls"]) == ['fillRect', 'setPen', 'drawPath', 'save', 'setRenderHint',
+                                               'setClipPath', 'fillPath', 'restore', 'end']
+
+
+@pytest.mark.parametrize("fixture", ["radialvs_mirror_wavy", "radialvs_plain_nosmooth"])
+def test_radial_view_state_paths_match_reference(fixture):
+    """Non-default view_state (mirror, waviness, audio-reactive envelope, feather rings, rotation, smoothing off)."""
+    import json
+    from oracle import radial_ref as RR
+    g = load_golden(fixture)
+    audio, sr, fps = g["audio"], int(g["sample_rate"]), int(g["fps"])
+    W, H = (int(v) for v in g["size"])
+    sens = float(g["sensitivity"])
+    vs = json.loads(str(g["view_state_json"]))
+    p = RR.RadialParams.from_view_state(vs, sens)
+    ref = A.analyze_track(audio, sr, fps, sensitivity=sens)
+    phase = A.phase_track(ref["energy"])
+    tr = RR.RadialTrack(p)
+    seen = 0
+    for f in range(ref["samples"].shape[0]):
+        e = float(ref["energy"][f])
+        path = tr.path(ref["logspec"][f], e, W, H)
+        key = f"f{f}"
+        if key + "_path" not in g.files:
+            continue
+        seen += 1
+        assert float(g[key + "_phase"]) == phase[f]
+        assert np.array_equal(path, g[key + "_path"]), (key, path.shape, g[key + "_path"].shape)
+        assert np.array_equal(RR.envelope_path(ref["logspec"][f], e, float(phase[f]), W, H, p), g[key + "_clip"])
+        rings = RR.feather_ring_paths(ref["logspec"][f], e, float(phase[f]), W, H, p)
+        fills = g[key + "_fill_rgba"]
+        assert tuple(fills[0]) == (30, 30, 40, 255) and len(fills) == 1 + len(rings)
+        for k, (verts, alpha) in enumerate(rings):
+            assert np.array_equal(verts, g[key + "_rings"][k])
+            assert tuple(fills[1 + k]) == (13, 13, 18, alpha)
+    assert seen == len(g["frames"])

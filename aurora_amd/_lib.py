@@ -21,6 +21,8 @@ SYMBOLS = (
     "aur_version", "aur_last_error", "aur_device_count", "aur_create", "aur_destroy", "aur_get_window",
     "aur_stft_frames", "aur_stft_buffer", "aur_log1p_f32", "aur_scan_frames",
     "aur_spans_spectrum_linear", "aur_spans_particles", "aur_spans_waveform_linear", "aur_raster_spans",
+    "aur_radial_stage1", "aur_radial_ema", "aur_radial_vertices", "aur_envelope_vertices",
+    "aur_mask_stroke_closed", "aur_mask_polygon", "aur_raster_planes",
     "aur_host_alloc", "aur_host_free", "aur_readback_async", "aur_stream_synchronize",
 )
 
@@ -64,6 +66,19 @@ class ScanParams(C.Structure):
         return p
 
 
+class EnvelopeParams(C.Structure):
+    """struct aur_envelope_params (include/aurora_hip.h)."""
+    _fields_ = [
+        ("radial_mirror", C.c_int),
+        ("edge_waviness", C.c_int),
+        ("feather_audio_enabled", C.c_int),
+        ("feather_audio_amount", C.c_int),
+        ("feather_sensitivity", C.c_double),
+        ("waveform_sensitivity", C.c_double),
+        ("rotation_rad", C.c_double),
+    ]
+
+
 _lock = threading.Lock()
 _lib = None
 
@@ -87,6 +102,14 @@ def _declare(lib):
     lib.aur_spans_particles.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.aur_spans_waveform_linear.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.aur_raster_spans.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp]
+    f64 = C.c_double
+    lib.aur_radial_stage1.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
+    lib.aur_radial_ema.argtypes = [vp, vp, i32, i32, f64, i32, vp, vp]
+    lib.aur_radial_vertices.argtypes = [vp, vp, vp, i32, i32, i32, vp, i32, i32, vp, i32, vp]
+    lib.aur_envelope_vertices.argtypes = [vp, vp, vp, vp, i32, C.POINTER(EnvelopeParams), vp, i32, i32, vp, vp]
+    lib.aur_mask_stroke_closed.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.aur_mask_polygon.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.aur_raster_planes.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.aur_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.aur_host_free.argtypes = [vp]
     lib.aur_readback_async.argtypes = [vp, vp, C.c_size_t, vp, vp]

@@ -1,0 +1,569 @@
+// "Spectrum - Radial" for gfx950 (MI355X): the radial spectrum path with its spatial / temporal smoothing, the
+// centre-disc ("feather") envelope, bit-plane rasterisation of both, and the RGB24 fill that composes them.
+//
+// Replaces widgets/rt_widget.py:942-981 (_draw_spectrum, radial branch), :1121-1137 (_smooth_closed),
+// :953-958 (_radial_prev temporal EMA), :1004-1051 + :1056-1096 (_draw_center_image_and_mask: envelope path and
+// QColor(30,30,40) fill) for the export entry point paint_frame (:821-852).
+//
+// Arithmetic follows the reference's numpy/Python expression order in float64 with contraction off (the library is
+// built with -ffp-contract=off), so vertices are bit-identical to the oracle for the export defaults:
+//  * np.interp on an integer grid: slope * (xi - j) + a[j] with slope = a[j+1] - a[j]; xi = i * step (np.linspace);
+//  * np.convolve with an all-equal kernel: sequential sum of a[i+k] * (1/win); numpy switches to an FMA dot product
+//    for kernels longer than 11 taps, which is mirrored here (win = 13 only occurs at amount = 100);
+//  * angles are host tables of (cos, sin) computed with the reference's own expression (index-map rule);
+//  * fbm / tanh of the envelope (only active with edge_waviness > 0) use the device libm: a few ulp, not bit-exact.
+// Coverage rule: oracle/raster_ref.py (pixel centre inside the closed outline; disc edge not antialiased).
+#include "common.h"
+
+namespace {
+
+constexpr double kBig = 1.0e6;
+constexpr int kMaxL = 4096;          // longest smoothed ring (158 * 5 * 5 = 3950)
+
+// ---- _smooth_closed (rt_widget.py:1121-1137) on an LDS array ------------------------------------------------------
+// in[L] -> out[L * up]; tmp[L * up] is scratch.  Whole block cooperates; ends with a barrier.
+__device__ void smooth_closed_lds(const double* in, int L, int amount, double step, double* tmp, double* out) {
+    const int up = 1 + amount / 25;
+    const int n = L * up;
+    const int half = (int)((double)amount * 0.06);
+    const int win = 2 * half + 1;
+    double* a = (win > 1) ? tmp : out;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double v;
+        if (up > 1) {
+            if (i == n - 1) {
+                v = in[L - 1];                                   // linspace endpoint == x[L-1]
+            } else {
+                const double xi = (double)i * step;
+                int j = (int)xi;
+                if (j > L - 2) j = L - 2;
+                const double xj = (double)j;
+                if (xj == xi) {
+                    v = in[j];
+                } else {
+                    const double slope = in[j + 1] - in[j];      // / (x[j+1] - x[j]) == 1
+                    v = slope * (xi - xj) + in[j];
+                }
+            }
+        } else {
+            v = in[i];
+        }
+        a[i] = v;
+    }
+    __syncthreads();
+    if (win > 1) {
+        const double c = 1.0 / (double)win;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            double s = 0.0;
+            if (win >= 12) {
+                for (int k = 0; k < win; ++k) {
+                    int idx = i - half + k;
+                    idx = (idx % n + n) % n;
+                    s = fma(a[idx], c, s);
+                }
+            } else {
+                for (int k = 0; k < win; ++k) {
+                    int idx = i - half + k;
+                    idx = (idx % n + n) % n;
+                    s = s + a[idx] * c;
+                }
+            }
+            out[i] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// spectrum[:80] / max -> (mirror) -> _smooth_closed(radial_wave_smoothness) -> vals1[f][L1]   (:938-951)
+__global__ __launch_bounds__(256) void radial_stage1_kernel(const float* __restrict__ logspec, int mirror,
+                                                            int amount1, double step1, int L0, int L1,
+                                                            double* __restrict__ vals1) {
+    __shared__ double s_a[160];
+    __shared__ double s_t[kMaxL / 4];
+    __shared__ double s_o[kMaxL / 4];
+    __shared__ float s_red[2];
+    const int f = blockIdx.x;
+    const float* spec = logspec + (long)f * AUR_NBINS;
+    float v = (threadIdx.x < AUR_N_BARS) ? spec[threadIdx.x] : -INFINITY;
+    if (threadIdx.x < 128) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    const float mxv = fmaxf(s_red[0], s_red[1]);
+    const float mx = (mxv > 0.0f) ? mxv : 1.0f;                  // rt_widget.py:939
+    if (threadIdx.x < AUR_N_BARS) {
+        const double n = (double)__fdiv_rn(spec[threadIdx.x], mx);   // float32 divide (:940), widened by _smooth_closed
+        s_a[threadIdx.x] = n;
+        // np.concatenate([spec, spec[::-1][1:-1]]): element 80 + m = spec[78 - m], m = 0..77   (:946)
+        if (mirror && threadIdx.x >= 1 && threadIdx.x <= AUR_N_BARS - 2) s_a[2 * AUR_N_BARS - 2 - threadIdx.x] = n;
+    }
+    __syncthreads();
+    double* dst = vals1 + (long)f * L1;
+    if (L0 > 3 && amount1 > 0) {
+        smooth_closed_lds(s_a, L0, amount1, step1, s_t, s_o);
+        for (int i = threadIdx.x; i < L1; i += blockDim.x) dst[i] = s_o[i];
+    } else {
+        for (int i = threadIdx.x; i < L1; i += blockDim.x) dst[i] = s_a[i];
+    }
+}
+
+// _radial_prev = alpha * _radial_prev + (1 - alpha) * spec_draw over consecutive frames, in place (:953-958).
+// One thread per ring element; the first frame of a track copies (prev is None), a shard continues from `state`.
+__global__ __launch_bounds__(256) void radial_ema_kernel(double* __restrict__ vals1, int n_frames, int L1,
+                                                         double alpha, int has_state, double* __restrict__ state) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L1) return;
+    const double beta = 1.0 - alpha;
+    double prev = has_state ? state[i] : 0.0;
+    int f = 0;
+    if (!has_state && n_frames > 0) {
+        prev = vals1[i];
+        f = 1;
+    }
+    for (; f < n_frames; ++f) {
+        const double cur = vals1[(long)f * L1 + i];
+        prev = alpha * prev + beta * cur;
+        vals1[(long)f * L1 + i] = prev;
+    }
+    state[i] = prev;
+}
+
+// _smooth_closed(radial_smooth_amount) -> r = inner + span * v -> (cx + cos a * r, cy + sin a * r)   (:960-974)
+__global__ __launch_bounds__(256) void radial_vertices_kernel(const double* __restrict__ vals1,
+                                                              const double* __restrict__ energy, int L1, int amount2,
+                                                              double step2, int L2, const double* __restrict__ cs,
+                                                              int W, int H, double* __restrict__ verts) {
+    extern __shared__ double s_dyn[];          // [L1] input ring, [L2] scratch, [L2] smoothed ring
+    double* s_a = s_dyn;
+    double* s_t = s_dyn + L1;
+    double* s_o = s_t + L2;
+    const int f = blockIdx.x;
+    const double* src = vals1 + (long)f * L1;
+    for (int i = threadIdx.x; i < L1; i += blockDim.x) s_a[i] = src[i];
+    __syncthreads();
+    const double* vals = s_a;
+    if (L1 > 3 && amount2 > 0) {
+        smooth_closed_lds(s_a, L1, amount2, step2, s_t, s_o);
+        vals = s_o;
+    }
+    const double mn = (double)(W < H ? W : H);
+    const double cx = (double)W / 2.0, cy = (double)H / 2.0;
+    const double inner = mn * 0.22;                               // :944
+    const double span = mn * 0.28 * (0.6 + 0.6 * energy[f]);      // :945
+    double* dst = verts + (long)f * (L2 + 1) * 2;
+    for (int i = threadIdx.x; i <= L2; i += blockDim.x) {
+        const double v = vals[i < L2 ? i : L2 - 1];               // spec_draw[min(i, L - 1)]
+        const double r = inner + span * v;
+        dst[2 * i] = cx + cs[2 * i] * r;
+        dst[2 * i + 1] = cy + cs[2 * i + 1] * r;
+    }
+}
+
+struct EnvArgs {
+    int mirror, W, H;
+    double noise_amt;      // edge_waviness / 100
+    double audio_amt;      // feather_audio_amount / 100 if enabled else 0
+    double sens_ratio;     // feather_sensitivity / max(1e-3, waveform_sensitivity)
+    double rot;            // np.deg2rad(radial_rotation_deg)
+};
+
+// Envelope of the centre disc: 361 vertices per frame (:1007-1051).
+__global__ __launch_bounds__(384) void envelope_vertices_kernel(const float* __restrict__ logspec,
+                                                                const double* __restrict__ energy,
+                                                                const double* __restrict__ phase, EnvArgs a,
+                                                                const double* __restrict__ cs360,
+                                                                double* __restrict__ verts) {
+    __shared__ float s_red[8];
+    const int f = blockIdx.x;
+    const float* spec = logspec + (long)f * AUR_NBINS;
+    const double mn = (double)(a.W < a.H ? a.W : a.H);
+    const double cx = (double)a.W / 2.0, cy = (double)a.H / 2.0;
+    const double inner = mn * 0.22;
+    float mxv = 0.0f;
+    if (a.audio_amt != 0.0) {     // max over the whole spectrum (:1024); skipped when the audio term is off
+        float m = -INFINITY;
+        for (int i = threadIdx.x; i < AUR_NBINS; i += blockDim.x) m = fmaxf(m, spec[i]);
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        mxv = s_red[0];
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) mxv = fmaxf(mxv, s_red[k]);
+    }
+    const float mx = (mxv > 1e-9f) ? mxv : 1.0f;
+    const double e = energy[f];
+    const double amp_noise_px = mn * 0.025 * a.noise_amt;                               // :1029
+    const double energy_feather = fmin(1.0, e * a.sens_ratio);                          // :1030
+    const double amp_audio_px = mn * 0.06 * a.audio_amt * (0.4 + 0.6 * energy_feather);  // :1031
+    const int i = threadIdx.x;
+    if (i > 360) return;
+    const int nlen = a.mirror ? 2 * AUR_NBINS - 2 : AUR_NBINS;
+    double s_val = 0.0;
+    if (a.audio_amt != 0.0) {
+        int si = (int)(((double)i / 360.0) * (double)(nlen - 1));                       // :1036
+        if (si >= AUR_NBINS) si = 2 * AUR_NBINS - 2 - si;      // mirrored tail: element 1025 + m = base[1023 - m]
+        s_val = (double)__fdiv_rn(spec[si], mx);
+    }
+    double fb = 0.0;
+    if (amp_noise_px != 0.0) {
+        const double ang = 2.0 * 3.141592653589793 * ((double)i / 360.0) - (3.141592653589793 / 2.0) + a.rot;
+        const double theta = ang * 2.0, ph = phase[f];
+        double v = 0.0, amp = 1.0, freq = 1.0;
+        for (int k = 0; k < 3; ++k) {                                                   // fbm, :1010-1018
+            v += amp * sin(freq * theta + (double)(k + 1) * ph);
+            amp *= 0.5;
+            freq *= 2.0;
+        }
+        fb = v / 1.75;
+    }
+    double r = inner + amp_noise_px * fb + amp_audio_px * s_val;                        // :1038
+    const double r_max = 0.48 * mn;
+    if (r_max > inner) {                                                                // :1041-1044
+        double g = fmax(0.0, (r - inner) / (r_max - inner));
+        if (g != 0.0) g = tanh(1.25 * g) / 0.84828363995751289761;    // math.tanh(1.25)
+        r = inner + g * (r_max - inner);
+    }
+    double* dst = verts + ((long)f * 361 + i) * 2;
+    dst[0] = cx + cs360[2 * i] * r;
+    dst[1] = cy + cs360[2 * i + 1] * r;
+}
+
+// ---- bit planes -------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void or_span(uint32_t* row, int c0, int c1, int W) {
+    if (c0 < 0) c0 = 0;
+    if (c1 > W) c1 = W;
+    if (c1 <= c0) return;
+    const int w0 = c0 >> 5, w1 = (c1 - 1) >> 5;
+    for (int w = w0; w <= w1; ++w) {
+        const int lo = (w == w0) ? (c0 & 31) : 0;
+        const int hi = (w == w1) ? ((c1 - 1) & 31) : 31;
+        const uint32_t bits = (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo);
+        atomicOr(row + w, bits);
+    }
+}
+
+// Rows of a convex polygon (n <= 4 vertices) OR-ed into a bit plane.
+__device__ void raster_convex(uint32_t* plane, int W32, const double* px, const double* py, int n, int W, int H) {
+    double ymin = py[0], ymax = py[0];
+    for (int i = 1; i < n; ++i) {
+        ymin = fmin(ymin, py[i]);
+        ymax = fmax(ymax, py[i]);
+    }
+    if (!(ymin == ymin) || !(ymax == ymax)) return;      // NaN vertices: nothing drawn
+    ymin = fmin(fmax(ymin, -kBig), kBig);
+    ymax = fmin(fmax(ymax, -kBig), kBig);
+    long r0 = (long)ceil(ymin - 0.5), r1 = (long)floor(ymax - 0.5) + 1;
+    if (r0 < 0) r0 = 0;
+    if (r1 > H) r1 = H;
+    for (long r = r0; r < r1; ++r) {
+        const double yc = (double)r + 0.5;
+        double xmin = kBig, xmax = -kBig;
+        bool hit = false;
+        for (int e = 0; e < n; ++e) {
+            const int e1 = (e + 1 == n) ? 0 : e + 1;
+            const double x0 = px[e], y0 = py[e], x1 = px[e1], y1 = py[e1];
+            if (y0 == y1) {
+                if (y0 == yc) {
+                    xmin = fmin(xmin, fmin(x0, x1));
+                    xmax = fmax(xmax, fmax(x0, x1));
+                    hit = true;
+                }
+            } else if ((yc - y0) * (yc - y1) <= 0.0) {
+                const double x = x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0);
+                xmin = fmin(xmin, x);
+                xmax = fmax(xmax, x);
+                hit = true;
+            }
+        }
+        if (!hit) continue;
+        xmin = fmin(fmax(xmin, -kBig), kBig);
+        xmax = fmin(fmax(xmax, -kBig), kBig);
+        or_span(plane + r * W32, (int)ceil(xmin - 0.5), (int)floor(xmax - 0.5) + 1, W);
+    }
+}
+
+__device__ __forceinline__ bool seg_dir(const double* V, int n, int s, double& ux, double& uy) {
+    const int s1 = (s + 1 == n) ? 0 : s + 1;
+    const double dx = V[2 * s1] - V[2 * s], dy = V[2 * s1 + 1] - V[2 * s + 1];
+    const double ln = sqrt(dx * dx + dy * dy);
+    if (ln == 0.0) return false;
+    ux = dx / ln;
+    uy = dy / ln;
+    return true;
+}
+
+// Width-2 BevelJoin stroke of the closed polygon verts[f][nv][2]: thread t < nv draws segment t, thread nv + t the
+// bevel at vertex t.  The plane must be zero on entry.
+__global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* __restrict__ verts, int nv, int W, int H,
+                                                                 int W32, uint32_t* __restrict__ planes) {
+    const int f = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= 2 * nv) return;
+    const double* V = verts + (long)f * nv * 2;
+    uint32_t* plane = planes + (long)f * H * W32;
+    double px[4], py[4];
+    if (t < nv) {
+        double ux, uy;
+        if (!seg_dir(V, nv, t, ux, uy)) return;
+        const int t1 = (t + 1 == nv) ? 0 : t + 1;
+        const double ax = V[2 * t], ay = V[2 * t + 1], bx = V[2 * t1], by = V[2 * t1 + 1];
+        const double nx = -uy, ny = ux;
+        px[0] = ax + nx; py[0] = ay + ny;
+        px[1] = bx + nx; py[1] = by + ny;
+        px[2] = bx - nx; py[2] = by - ny;
+        px[3] = ax - nx; py[3] = ay - ny;
+        raster_convex(plane, W32, px, py, 4, W, H);
+    } else {
+        const int v = t - nv;
+        const int a = (v == 0) ? nv - 1 : v - 1;
+        double uxa, uya, uxb, uyb;
+        if (!seg_dir(V, nv, a, uxa, uya) || !seg_dir(V, nv, v, uxb, uyb)) return;
+        const double cr = uxa * uyb - uya * uxb;
+        if (cr == 0.0) return;
+        const double sg = (cr > 0.0) ? -1.0 : 1.0;
+        const double vx = V[2 * v], vy = V[2 * v + 1];
+        px[0] = vx; py[0] = vy;
+        px[1] = vx + sg * (-uya); py[1] = vy + sg * uxa;
+        px[2] = vx + sg * (-uyb); py[2] = vy + sg * uxb;
+        raster_convex(plane, W32, px, py, 3, W, H);
+    }
+}
+
+constexpr int kMaxCross = 64;
+
+// Even-odd fill of the implicitly closed polygon verts[f][nv][2], one thread per pixel row.  Plane zero on entry.
+__global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restrict__ verts, int nv, int W, int H,
+                                                           int W32, uint32_t* __restrict__ planes) {
+    const int f = blockIdx.y;
+    const int r = blockIdx.x * 128 + threadIdx.x;
+    if (r >= H) return;
+    const double* V = verts + (long)f * nv * 2;
+    uint32_t* row = planes + ((long)f * H + r) * W32;
+    const double yc = (double)r + 0.5;
+    double xs[kMaxCross];
+    int m = 0;
+    for (int e = 0; e < nv; ++e) {
+        const int e1 = (e + 1 == nv) ? 0 : e + 1;
+        const double x0 = V[2 * e], y0 = V[2 * e + 1], x1 = V[2 * e1], y1 = V[2 * e1 + 1];
+        if ((y0 <= yc) != (y1 <= yc)) {
+            const double x = x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0);
+            if (m < kMaxCross) {
+                int k = m++;
+                while (k > 0 && xs[k - 1] > x) {      // insertion sort
+                    xs[k] = xs[k - 1];
+                    --k;
+                }
+                xs[k] = x;
+            }
+        }
+    }
+    for (int i = 0; i + 1 < m; i += 2) {
+        const double a = fmin(fmax(xs[i], -kBig), kBig), b = fmin(fmax(xs[i + 1], -kBig), kBig);
+        or_span(row, (int)ceil(a - 0.5), (int)ceil(b - 0.5), W);
+    }
+}
+
+// ---- fill: two bit planes -> RGB24 (same 16-byte-column layout as raster_fill16_kernel) -----------------------------
+
+constexpr uint32_t kBg24 = 13u | (13u << 8) | (18u << 16);     // rt_widget.py:829
+constexpr uint32_t kDisc24 = 30u | (30u << 8) | (40u << 16);   // rt_widget.py:1092/1094
+constexpr int kRowsPerTask = 16;
+
+__device__ __forceinline__ uint4 pack_rgb16(const uint32_t (&P)[6], int ph) {
+    const uint32_t s0 = P[0] | (P[1] << 24);
+    const uint32_t s1 = (P[1] >> 8) | (P[2] << 16);
+    const uint32_t s2 = (P[2] >> 16) | (P[3] << 8);
+    const uint32_t s3 = P[4] | (P[5] << 24);
+    const uint32_t s4 = P[5] >> 8;
+    uint4 o;
+    o.x = __builtin_amdgcn_alignbyte(s1, s0, ph);
+    o.y = __builtin_amdgcn_alignbyte(s2, s1, ph);
+    o.z = __builtin_amdgcn_alignbyte(s3, s2, ph);
+    o.w = __builtin_amdgcn_alignbyte(s4, s3, ph);
+    return o;
+}
+
+__global__ __launch_bounds__(256) void raster_fill_planes_kernel(const uint32_t* __restrict__ stroke,
+                                                                 const uint32_t* __restrict__ disc,
+                                                                 const uint32_t* __restrict__ pen_rgb, int W, int H,
+                                                                 int W32, int nu4, int nchunks,
+                                                                 uint4* __restrict__ frames) {
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int chunk = task % nchunks, tile = task / nchunks;
+    const int row0 = tile * kRowsPerTask;
+    const int i = chunk * 64 + lane;
+    if (row0 >= H || i >= nu4) return;
+    const int row1 = (row0 + kRowsPerTask < H) ? row0 + kRowsPerTask : H;
+    const int c0 = (16 * i) / 3, ph = i % 3;
+    const uint32_t pen = pen_rgb[f] & 0x00ffffffu;
+    const int wA = c0 >> 5, sh = c0 & 31;
+    const int wB = (wA + 1 < W32) ? wA + 1 : wA;
+    const uint32_t Pbg[6] = {kBg24, kBg24, kBg24, kBg24, kBg24, kBg24};
+    const uint4 bgv = pack_rgb16(Pbg, ph);
+    const uint32_t* srow = stroke + ((long)f * H + row0) * W32;
+    const uint32_t* drow = disc + ((long)f * H + row0) * W32;
+    uint4* dst = frames + ((long)f * H + row0) * (long)nu4 + i;
+    for (int row = row0; row < row1; ++row) {
+        const uint64_t sb = (((uint64_t)srow[wB] << 32) | srow[wA]) >> sh;
+        const uint64_t db = (((uint64_t)drow[wB] << 32) | drow[wA]) >> sh;
+        uint4 o = bgv;
+        if (((sb | db) & 0x3fu) != 0) {
+            uint32_t P[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                P[c] = ((db >> c) & 1u) ? kDisc24 : (((sb >> c) & 1u) ? pen : kBg24);   // disc is painted last
+            o = pack_rgb16(P, ph);
+        }
+        *dst = o;
+        dst += nu4;
+        srow += W32;
+        drow += W32;
+    }
+}
+
+}  // namespace
+
+extern "C" int aur_radial_stage1(aur_ctx* ctx, const float* d_logspec, int n_frames, int mirror, int wave_smoothness,
+                                 double* d_vals1, int L1, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0, "aur_radial_stage1: n_frames %d < 0", n_frames);
+    AUR_REQUIRE(wave_smoothness >= 0 && wave_smoothness <= 100, "aur_radial_stage1: smoothness %d outside [0, 100]",
+                wave_smoothness);
+    const int L0 = mirror ? 2 * AUR_N_BARS - 2 : AUR_N_BARS;
+    const int up = (wave_smoothness > 0) ? 1 + wave_smoothness / 25 : 1;
+    AUR_REQUIRE(L1 == L0 * up, "aur_radial_stage1: L1 %d != %d", L1, L0 * up);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_logspec && d_vals1, "aur_radial_stage1: null device pointer");
+    const double step = (double)(L0 - 1) / (double)(L0 * up - 1);     // np.linspace(0, L - 1, L * up) step
+    hipLaunchKernelGGL(radial_stage1_kernel, dim3(n_frames), dim3(256), 0, (hipStream_t)stream, d_logspec, mirror,
+                       wave_smoothness, step, L0, L1, d_vals1);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_radial_ema(aur_ctx* ctx, double* d_vals1, int n_frames, int L1, double alpha, int has_state,
+                              double* d_state, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && L1 > 0 && L1 <= kMaxL / 4, "aur_radial_ema: bad shape F=%d L1=%d", n_frames, L1);
+    AUR_REQUIRE(alpha > 0.0 && alpha <= 0.95, "aur_radial_ema: alpha %g outside (0, 0.95]", alpha);
+    AUR_REQUIRE(d_vals1 && d_state, "aur_radial_ema: null device pointer");
+    hipLaunchKernelGGL(radial_ema_kernel, dim3((L1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_vals1, n_frames,
+                       L1, alpha, has_state, d_state);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_radial_vertices(aur_ctx* ctx, const double* d_vals1, const double* d_energy, int n_frames, int L1,
+                                   int smooth_amount, const double* d_cos_sin, int W, int H, double* d_verts, int L2,
+                                   void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && L1 > 0 && L1 <= kMaxL / 4, "aur_radial_vertices: bad shape F=%d L1=%d", n_frames, L1);
+    AUR_REQUIRE(smooth_amount >= 0 && smooth_amount <= 100, "aur_radial_vertices: amount %d outside [0, 100]",
+                smooth_amount);
+    const int up = (L1 > 3 && smooth_amount > 0) ? 1 + smooth_amount / 25 : 1;
+    AUR_REQUIRE(L2 == L1 * up && L2 <= kMaxL, "aur_radial_vertices: L2 %d != %d", L2, L1 * up);
+    AUR_REQUIRE(W >= 16 && H >= 16, "aur_radial_vertices: frame %dx%d too small", W, H);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_vals1 && d_energy && d_cos_sin && d_verts, "aur_radial_vertices: null device pointer");
+    const double step = (double)(L1 - 1) / (double)(L1 * up - 1);
+    const int lds = (L1 + 2 * L2) * (int)sizeof(double);
+    AUR_CHECK_HIP(hipFuncSetAttribute((const void*)radial_vertices_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      lds));
+    hipLaunchKernelGGL(radial_vertices_kernel, dim3(n_frames), dim3(256), lds, (hipStream_t)stream, d_vals1, d_energy,
+                       L1, smooth_amount, step, L2, d_cos_sin, W, H, d_verts);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_envelope_vertices(aur_ctx* ctx, const float* d_logspec, const double* d_energy,
+                                     const double* d_phase, int n_frames, const aur_envelope_params* p,
+                                     const double* d_cos_sin360, int W, int H, double* d_verts, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(p != nullptr, "aur_envelope_vertices: null params");
+    AUR_REQUIRE(n_frames >= 0, "aur_envelope_vertices: n_frames %d < 0", n_frames);
+    AUR_REQUIRE(W >= 16 && H >= 16, "aur_envelope_vertices: frame %dx%d too small", W, H);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_logspec && d_energy && d_phase && d_cos_sin360 && d_verts, "aur_envelope_vertices: null device pointer");
+    EnvArgs a;
+    a.mirror = p->radial_mirror ? 1 : 0;
+    a.W = W;
+    a.H = H;
+    a.noise_amt = (double)p->edge_waviness / 100.0;
+    a.audio_amt = p->feather_audio_enabled ? (double)p->feather_audio_amount / 100.0 : 0.0;
+    a.sens_ratio = p->feather_sensitivity / fmax(1e-3, p->waveform_sensitivity);
+    a.rot = p->rotation_rad;
+    hipLaunchKernelGGL(envelope_vertices_kernel, dim3(n_frames), dim3(384), 0, (hipStream_t)stream, d_logspec, d_energy,
+                       d_phase, a, d_cos_sin360, d_verts);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+static int check_plane_args(const char* who, int n_frames, int nv, int W, int H) {
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "%s: n_frames %d outside [0, 65535]", who, n_frames);
+    AUR_REQUIRE(nv >= 3 && nv <= kMaxL + 1, "%s: %d vertices outside [3, %d]", who, nv, kMaxL + 1);
+    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "%s: frame size %dx%d outside [16..16384]^2", who, W, H);
+    return AUR_OK;
+}
+
+extern "C" int aur_mask_stroke_closed(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
+                                      uint32_t* d_plane, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_plane_args("aur_mask_stroke_closed", n_frames, n_vertices, W, H))) return rc;
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_verts && d_plane, "aur_mask_stroke_closed: null device pointer");
+    const int W32 = (W + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    AUR_CHECK_HIP(hipMemsetAsync(d_plane, 0, (size_t)n_frames * H * W32 * 4, st));
+    hipLaunchKernelGGL(mask_stroke_closed_kernel, dim3((2 * n_vertices + 255) / 256, n_frames), dim3(256), 0, st,
+                       d_verts, n_vertices, W, H, W32, d_plane);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
+                                uint32_t* d_plane, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_plane_args("aur_mask_polygon", n_frames, n_vertices, W, H))) return rc;
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_verts && d_plane, "aur_mask_polygon: null device pointer");
+    const int W32 = (W + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    AUR_CHECK_HIP(hipMemsetAsync(d_plane, 0, (size_t)n_frames * H * W32 * 4, st));
+    hipLaunchKernelGGL(mask_polygon_kernel, dim3((H + 127) / 128, n_frames), dim3(128), 0, st, d_verts, n_vertices, W,
+                       H, W32, d_plane);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, const uint32_t* d_disc_plane,
+                                 const uint8_t* d_pen_rgb, int n_frames, int W, int H, uint8_t* d_frames,
+                                 void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_raster_planes: n_frames %d outside [0, 65535]", n_frames);
+    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_raster_planes: frame size %dx%d unsupported", W, H);
+    AUR_REQUIRE(W % 16 == 0, "aur_raster_planes: width %d must be a multiple of 16", W);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_stroke_plane && d_disc_plane && d_pen_rgb && d_frames, "aur_raster_planes: null device pointer");
+    AUR_REQUIRE(((uintptr_t)d_frames & 15u) == 0 && ((uintptr_t)d_pen_rgb & 3u) == 0,
+                "aur_raster_planes: misaligned device pointer");
+    const int W32 = (W + 31) / 32;
+    const int nu4 = W * 3 / 16, nchunks = (nu4 + 63) / 64;
+    const int ntiles = (H + kRowsPerTask - 1) / kRowsPerTask;
+    hipLaunchKernelGGL(raster_fill_planes_kernel, dim3((nchunks * ntiles + 3) / 4, n_frames), dim3(256), 0,
+                       (hipStream_t)stream, d_stroke_plane, d_disc_plane, reinterpret_cast<const uint32_t*>(d_pen_rgb), W,
+                       H, W32, nu4, nchunks, reinterpret_cast<uint4*>(d_frames));
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}

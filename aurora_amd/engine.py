@@ -49,7 +49,75 @@ def mode_kind(mode: str) -> str:
     return "particles"
 
 
-SUPPORTED_KINDS = ("spectrum_linear", "waveform_linear", "particles")
+SUPPORTED_KINDS = ("spectrum_linear", "waveform_linear", "particles", "spectrum_radial")
+
+
+@dataclass
+class RadialConfig:
+    """Settings of "Spectrum - Radial" as an export sees them: widget defaults (rt_widget.py:59-67, :106-114)
+    overridden by the exporter's _apply_view_state (export/exporter.py:153-209)."""
+    radial_rotation_deg: float = 0.0
+    radial_mirror: bool = False
+    radial_smooth_amount: int = 50
+    radial_wave_smoothness: int = 50
+    radial_temporal_alpha: float = 0.3
+    edge_waviness: int = 0
+    feather_enabled: bool = False
+    feather_audio_enabled: bool = False
+    feather_audio_amount: int = 0
+    feather_sensitivity: float = 2.0
+    waveform_sensitivity: float = 1.0
+
+    @classmethod
+    def from_view_state(cls, vs, sensitivity=1.0):
+        vs = vs or {}
+        c = cls()
+        c.radial_rotation_deg = float(vs.get("radial_rotation_deg", 0.0))
+        c.radial_mirror = bool(vs.get("radial_mirror", False))
+        c.radial_smooth_amount = max(0, min(100, int(vs.get("radial_smooth_amount", 50))))
+        if "radial_waveform_smoothness" in vs:
+            c.radial_wave_smoothness = max(0, min(100, int(vs["radial_waveform_smoothness"])))
+        if "radial_temporal_smoothing" in vs:
+            c.radial_temporal_alpha = max(0.0, min(0.95, int(vs["radial_temporal_smoothing"]) / 100.0))
+        c.edge_waviness = max(0, min(100, int(vs.get("edge_waviness", 0))))
+        c.feather_enabled = bool(vs.get("feather_enabled", False))
+        c.feather_audio_enabled = bool(vs.get("feather_audio_enabled", False))
+        c.feather_audio_amount = max(0, min(100, int(vs.get("feather_audio_amount", 0))))
+        c.waveform_sensitivity = max(0.05, float(sensitivity))
+        return c
+
+    # ring lengths after mirror / _smooth_closed #1 / _smooth_closed #2 (rt_widget.py:946-962, :1125)
+    @property
+    def L0(self):
+        return 158 if self.radial_mirror else 80
+
+    @property
+    def L1(self):
+        return self.L0 * (1 + self.radial_wave_smoothness // 25 if self.radial_wave_smoothness > 0 else 1)
+
+    @property
+    def L2(self):
+        return self.L1 * (1 + self.radial_smooth_amount // 25 if self.radial_smooth_amount > 0 else 1)
+
+
+def angle_table(n: int, rotation_deg: float) -> np.ndarray:
+    """(cos a_i, sin a_i), a_i = 2 pi (i / n) - pi / 2 + deg2rad(rot), i = 0..n, float64 [n + 1, 2], evaluated with the
+    reference's expression and scalar calls (rt_widget.py:966, :1035) -- an index-map-like table, so it is exact."""
+    out = np.empty((n + 1, 2), dtype=np.float64)
+    for i in range(n + 1):
+        a = 2.0 * np.pi * (i / n) - (np.pi / 2.0) + np.deg2rad(rotation_deg)
+        out[i, 0] = np.cos(a)
+        out[i, 1] = np.sin(a)
+    return out
+
+
+@dataclass
+class RadialPrep:
+    cfg: RadialConfig
+    vals1: "torch.Tensor"        # float64 [F, L1]: ring after stage 1 and the temporal EMA
+    state: "torch.Tensor"        # float64 [L1]: EMA state after the last frame
+    cos_sin: "torch.Tensor"      # float64 [L2 + 1, 2]
+    cos_sin360: "torch.Tensor"   # float64 [361, 2]
 
 
 def _ptr(t):
@@ -237,6 +305,85 @@ class HipExportEngine:
             count = an.n_frames - first
         spans, K = self.spans(kind, an, sc, W, H, first, count, out=spans_out)
         return self.fill(spans, K, sc.pen_rgb[first:first + count], W, H, out=out)
+
+    # ------------------------------------------------------------------ Spectrum - Radial
+    def radial_prepare(self, an: Analysis, cfg: RadialConfig, state=None) -> RadialPrep:
+        """Ring values of every analysed frame (stage 1 + temporal EMA).  state: None at track start, else the
+        float64 [L1] EMA state carried from the frames before ``an.frame_begin``."""
+        torch = self.torch
+        if cfg.feather_enabled:
+            raise NotImplementedError("feather rings (view_state['feather_enabled']) are not implemented on the HIP path")
+        F, L1 = an.n_frames, cfg.L1
+        vals1 = self.empty((F, L1), torch.float64)
+        h, st = self.ctx.handle, self.stream()
+        _lib.check(self.lib.aur_radial_stage1(h, _ptr(an.logspec), F, int(cfg.radial_mirror),
+                                              int(cfg.radial_wave_smoothness), _ptr(vals1), L1, st), "aur_radial_stage1")
+        st_t = self.empty((L1,), torch.float64)
+        if cfg.radial_temporal_alpha > 0.0:
+            has = state is not None
+            if has:
+                st_t.copy_(state)
+            _lib.check(self.lib.aur_radial_ema(h, _ptr(vals1), F, L1, float(cfg.radial_temporal_alpha), int(has),
+                                               _ptr(st_t), st), "aur_radial_ema")
+        key = ("radial", cfg.L2, cfg.radial_rotation_deg)
+        if key not in self._col2samp:
+            self._col2samp[key] = (torch.from_numpy(angle_table(cfg.L2, cfg.radial_rotation_deg)).to(self.device),
+                                   torch.from_numpy(angle_table(360, cfg.radial_rotation_deg)).to(self.device))
+        cs, cs360 = self._col2samp[key]
+        return RadialPrep(cfg, vals1, st_t, cs, cs360)
+
+    def carried_radial_state(self, track: Track, frame_begin: int, cfg: RadialConfig, chunk: int = 16384):
+        """EMA state of the radial ring in front of ``frame_begin`` (analysis-only pre-pass over [0, frame_begin))."""
+        if frame_begin <= 0 or cfg.radial_temporal_alpha <= 0.0:
+            return None
+        state, f = None, 0
+        while f < frame_begin:
+            n = min(chunk, frame_begin - f)
+            prep = self.radial_prepare(self.analyze(track, f, n), cfg, state)
+            state = prep.state
+            f += n
+        return state
+
+    def radial_vertices(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int):
+        """(path float64 [count, L2 + 1, 2], envelope float64 [count, 361, 2]) of frames first .. first + count."""
+        torch, cfg = self.torch, prep.cfg
+        h, st = self.ctx.handle, self.stream()
+        L1, L2 = cfg.L1, cfg.L2
+        verts = self.empty((count, L2 + 1, 2), torch.float64)
+        energy = sc.energy[first:first + count]
+        _lib.check(self.lib.aur_radial_vertices(h, _ptr(prep.vals1[first:first + count]), _ptr(energy), count, L1,
+                                                int(cfg.radial_smooth_amount), _ptr(prep.cos_sin), W, H, _ptr(verts),
+                                                L2, st), "aur_radial_vertices")
+        ep = _lib.EnvelopeParams(int(cfg.radial_mirror), int(cfg.edge_waviness), int(cfg.feather_audio_enabled),
+                                 int(cfg.feather_audio_amount), float(cfg.feather_sensitivity),
+                                 float(cfg.waveform_sensitivity), float(np.deg2rad(cfg.radial_rotation_deg)))
+        env = self.empty((count, 361, 2), torch.float64)
+        _lib.check(self.lib.aur_envelope_vertices(h, _ptr(an.logspec[first:first + count]), _ptr(energy),
+                                                  _ptr(sc.phase[first:first + count]), count, C.byref(ep),
+                                                  _ptr(prep.cos_sin360), W, H, _ptr(env), st), "aur_envelope_vertices")
+        return verts, env
+
+    def render_radial(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int = 0,
+                      count: int | None = None, out=None, planes_out=None):
+        """Frames uint8 [count, H, W, 3] of "Spectrum - Radial" (paint_frame, rt_widget.py:821-852)."""
+        torch = self.torch
+        if count is None:
+            count = an.n_frames - first
+        verts, env = self.radial_vertices(prep, an, sc, W, H, first, count)
+        W32 = (W + 31) // 32
+        if planes_out is None:
+            planes_out = self.empty((2, count, H, W32), torch.int32)
+        h, st = self.ctx.handle, self.stream()
+        _lib.check(self.lib.aur_mask_stroke_closed(h, _ptr(verts), int(verts.shape[1]), count, W, H,
+                                                   _ptr(planes_out[0]), st), "aur_mask_stroke_closed")
+        _lib.check(self.lib.aur_mask_polygon(h, _ptr(env), 361, count, W, H, _ptr(planes_out[1]), st),
+                   "aur_mask_polygon")
+        if out is None:
+            out = self.empty((count, H, W, 3), torch.uint8)
+        _lib.check(self.lib.aur_raster_planes(h, _ptr(planes_out[0]), _ptr(planes_out[1]),
+                                              _ptr(sc.pen_rgb[first:first + count]), count, W, H, _ptr(out), st),
+                   "aur_raster_planes")
+        return out
 
     # ------------------------------------------------------------------ streaming Analyzer step
     def stft_buffer(self, d_buffer, d_prev_mag, d_logspec, d_flux_sum):

@@ -28,7 +28,7 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from ..engine import get_engine, mode_kind, SUPPORTED_KINDS
+from ..engine import RadialConfig, get_engine, mode_kind, SUPPORTED_KINDS
 from ..pipeline import FramePipeline
 
 logger = logging.getLogger(__name__)
@@ -122,9 +122,11 @@ class HipOffscreenRenderer:
         kind = mode_kind(self.mode)
         if kind not in SUPPORTED_KINDS:
             raise NotImplementedError(f"mode {self.mode!r} is not implemented on the HIP export path yet")
-        for key in ("background_path", "glow_enabled", "shadow_enabled", "radial_fill_enabled"):
+        for key in ("background_path", "glow_enabled", "shadow_enabled", "radial_fill_enabled", "center_image_path",
+                    "feather_enabled"):
             if view_state.get(key):
                 raise NotImplementedError(f"view_state[{key!r}] is not implemented on the HIP export path yet")
+        radial = RadialConfig.from_view_state(view_state, self.sensitivity) if kind == "spectrum_radial" else None
 
         device = int(view_state.get("hip_device", 0) or 0)
         self._eng = get_engine(device)
@@ -142,7 +144,7 @@ class HipOffscreenRenderer:
         self.frame_begin, self.frame_end = max(0, f0), min(self.total_frames, f1)
         self._pipe = FramePipeline(self._eng, self._track, self.mode, self.width, self.height, self.sensitivity,
                                    self.frame_begin, self.frame_end,
-                                   batch_frames=view_state.get("hip_batch_frames"))
+                                   batch_frames=view_state.get("hip_batch_frames"), radial=radial)
         self._cache = None          # (first_frame, uint8 [n, H, W, 3] host array)
 
     # -- batched fast path used by Exporter._run_pipe ---------------------------------------------------

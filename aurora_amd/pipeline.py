@@ -19,7 +19,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from .engine import HipExportEngine, Track, mode_kind, SUPPORTED_KINDS
+from .engine import HipExportEngine, RadialConfig, Track, mode_kind, SUPPORTED_KINDS
 
 
 class NullSink:
@@ -69,7 +69,8 @@ def default_batch_frames(W: int, H: int, budget_bytes: int = 1 << 30) -> int:
 class FramePipeline:
     def __init__(self, engine: HipExportEngine, track: Track, mode: str, width: int, height: int,
                  sensitivity: float = 1.0, frame_begin: int = 0, frame_end: int | None = None,
-                 batch_frames: int | None = None, slots: int = 2, scan_params: _lib.ScanParams | None = None):
+                 batch_frames: int | None = None, slots: int = 2, scan_params: _lib.ScanParams | None = None,
+                 radial: "RadialConfig | None" = None):
         self.eng = engine
         self.track = track
         self.mode = mode
@@ -85,7 +86,9 @@ class FramePipeline:
         self.slots = int(max(1, slots))
         self.params = scan_params or _lib.ScanParams.defaults(sensitivity)
         self.frame_bytes = self.W * self.H * 3
+        self.radial = (radial or RadialConfig.from_view_state(None, sensitivity)) if self.kind == "spectrum_radial" else None
         self._analysed = None
+        self._radial_prep = None
 
     # ---- phase 1: analysis + scan of the whole shard (about 10 KB per frame) -------------------------
     def analyse(self):
@@ -95,13 +98,22 @@ class FramePipeline:
             n = self.frame_end - self.frame_begin
             an = eng.analyze(self.track, self.frame_begin, n, want_samples=(self.kind == "waveform_linear"))
             sc = eng.scan(an, self.params, state)
+            if self.radial is not None:
+                rstate = eng.carried_radial_state(self.track, self.frame_begin, self.radial)
+                self._radial_prep = eng.radial_prepare(an, self.radial, rstate)
             self._analysed = (an, sc)
         return self._analysed
 
     # ---- device-only rendering (benchmark "value": frames stay in HBM) ----------------------------------
     def render_device(self, out=None, spans_out=None, first: int = 0, count: int | None = None):
         an, sc = self.analyse()
-        return self.eng.render(self.mode, an, sc, self.W, self.H, first, count, out=out, spans_out=spans_out)
+        return self._render(an, sc, first, count, out, spans_out)
+
+    def _render(self, an, sc, first, count, out=None, scratch=None):
+        if self.radial is not None:
+            return self.eng.render_radial(self._radial_prep, an, sc, self.W, self.H, first, count, out=out,
+                                          planes_out=scratch)
+        return self.eng.render(self.mode, an, sc, self.W, self.H, first, count, out=out, spans_out=scratch)
 
     # ---- full pipeline: GPU -> pinned host ring -> sink --------------------------------------------------
     def run(self, sink, progress=None):
@@ -112,10 +124,13 @@ class FramePipeline:
         if n_total == 0:
             return 0
         B, S = min(self.batch, n_total), self.slots
-        K = {"spectrum_linear": _lib.K_SPECTRUM, "particles": _lib.K_PARTICLES,
-             "waveform_linear": _lib.K_WAVEFORM}[self.kind]
         dev_frames = [eng.empty((B, self.H, self.W, 3), torch.uint8) for _ in range(S)]
-        dev_spans = [eng.empty((B, K, self.W), torch.int32) for _ in range(S)]
+        if self.radial is not None:
+            dev_spans = [eng.empty((2, B, self.H, (self.W + 31) // 32), torch.int32) for _ in range(S)]
+        else:
+            K = {"spectrum_linear": _lib.K_SPECTRUM, "particles": _lib.K_PARTICLES,
+                 "waveform_linear": _lib.K_WAVEFORM}[self.kind]
+            dev_spans = [eng.empty((B, K, self.W), torch.int32) for _ in range(S)]
         host = [_PinnedSlot(eng.lib, B * self.frame_bytes) for _ in range(S)]
         copy_stream = torch.cuda.Stream(device=eng.device)
         copied = [None] * S                    # event: slot's D2H copy finished
@@ -158,8 +173,8 @@ class FramePipeline:
                 cur = torch.cuda.current_stream(eng.device)
                 if copied[slot] is not None:
                     cur.wait_event(copied[slot])           # device slot no longer being read by the copy engine
-                eng.render(self.mode, an, sc, self.W, self.H, done, n, out=dev_frames[slot][:n],
-                           spans_out=dev_spans[slot][:n])
+                self._render(an, sc, done, n, out=dev_frames[slot][:n],
+                             scratch=dev_spans[slot][:, :n] if self.radial is not None else dev_spans[slot][:n])
                 rendered = torch.cuda.Event()
                 rendered.record(cur)
                 copy_stream.wait_event(rendered)

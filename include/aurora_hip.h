@@ -157,6 +157,64 @@ int aur_spans_waveform_linear(aur_ctx* ctx, const float* d_samples /*[F,1024]*/,
 int aur_raster_spans(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb /*[F,4]*/,
                      int n_frames, int W, int H, uint8_t* d_frames, void* stream);
 
+/* ---- "Spectrum - Radial": radial path, centre-disc envelope, bit planes ------------------------------------ */
+
+/* Stage 1 of the radial spectrum (rt_widget.py:938-951): spectrum[:80] / max (float32) -> optional mirror
+ * (np.concatenate([spec, spec[::-1][1:-1]])) -> _smooth_closed(radial_wave_smoothness) (rt_widget.py:1121-1137).
+ * d_vals1: float64 [n_frames, L1], L1 = (mirror ? 158 : 80) * (1 + wave_smoothness / 25)  (x1 if smoothness == 0). */
+int aur_radial_stage1(aur_ctx* ctx, const float* d_logspec /*[F,1025]*/, int n_frames, int mirror,
+                      int wave_smoothness, double* d_vals1, int L1, void* stream);
+
+/* The _radial_prev temporal EMA (rt_widget.py:953-958) over consecutive frames, in place on d_vals1:
+ *   prev = alpha * prev + (1 - alpha) * cur;  the first frame copies when has_state == 0 (prev is None).
+ * d_state: float64 [L1], read when has_state != 0 (carried state of the previous time shard), always written with
+ * the state after the last frame.  Skip the call when alpha == 0 (the reference skips the block). */
+int aur_radial_ema(aur_ctx* ctx, double* d_vals1, int n_frames, int L1, double alpha, int has_state, double* d_state,
+                   void* stream);
+
+/* Stage 2 (rt_widget.py:960-974): _smooth_closed(radial_smooth_amount) -> L2 + 1 vertices per frame,
+ *   r = inner + span * v, (x, y) = (W/2 + cos(a_i) * r, H/2 + sin(a_i) * r), i = 0..L2, v = spec_draw[min(i, L2-1)].
+ * d_cos_sin: float64 [L2 + 1, 2] = (cos a_i, sin a_i), a_i = 2 pi (i / L2) - pi/2 + deg2rad(rotation), computed on the
+ * host with the reference's expression (rt_widget.py:966).  d_verts: float64 [n_frames, L2 + 1, 2].
+ * L2 = L1 * (1 + smooth_amount / 25)  (x1 if smooth_amount == 0 or L1 <= 3). */
+int aur_radial_vertices(aur_ctx* ctx, const double* d_vals1, const double* d_energy, int n_frames, int L1,
+                        int smooth_amount, const double* d_cos_sin, int W, int H, double* d_verts, int L2,
+                        void* stream);
+
+typedef struct aur_envelope_params {
+    int    radial_mirror;          /* rt_widget.py:1026 */
+    int    edge_waviness;          /* 0..100, rt_widget.py:1020 */
+    int    feather_audio_enabled;  /* rt_widget.py:1021 */
+    int    feather_audio_amount;   /* 0..100 */
+    double feather_sensitivity;    /* rt_widget.py:60, :1030 */
+    double waveform_sensitivity;   /* rt_widget.py:59, :1030 */
+    double rotation_rad;           /* np.deg2rad(radial_rotation_deg), rt_widget.py:1035 */
+} aur_envelope_params;
+
+/* Envelope of the centre disc, `_draw_center_image_and_mask` (rt_widget.py:1007-1051): 361 vertices per frame,
+ *   r = inner + amp_noise * fbm(2 a, phase) + amp_audio * spec_norm[si], soft-limited by tanh.
+ * d_cos_sin360: float64 [361, 2] host table of (cos a_i, sin a_i), a_i = 2 pi (i / 360) - pi/2 + rotation.
+ * d_verts: float64 [n_frames, 361, 2]. */
+int aur_envelope_vertices(aur_ctx* ctx, const float* d_logspec, const double* d_energy, const double* d_phase,
+                          int n_frames, const aur_envelope_params* params, const double* d_cos_sin360, int W, int H,
+                          double* d_verts, void* stream);
+
+/* Bit planes: uint32 [n_frames, H, ceil(W/32)], bit (x & 31) of word (x >> 5) = pixel (x, row) is covered.
+ * aur_mask_stroke_closed: width-2 BevelJoin stroke of the closed polygon through d_verts [F, n_vertices, 2]
+ *   (`p.drawPath(path)` with the width-2 pen, rt_widget.py:975-981);
+ * aur_mask_polygon: even-odd fill of the implicitly closed polygon, sampled at pixel centres
+ *   (`p.fillPath(path, QColor(30,30,40))` under the clip, rt_widget.py:1056-1096; edge antialiasing not reproduced).
+ * Both clear the plane first. */
+int aur_mask_stroke_closed(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
+                           uint32_t* d_plane, void* stream);
+int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
+                     uint32_t* d_plane, void* stream);
+
+/* RGB24 frames of "Spectrum - Radial" (paint_frame, rt_widget.py:821-852): background (13,13,18), stroke plane in the
+ * pen colour, disc plane in (30,30,40) on top.  W must be a multiple of 16. */
+int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, const uint32_t* d_disc_plane,
+                      const uint8_t* d_pen_rgb /*[F,4]*/, int n_frames, int W, int H, uint8_t* d_frames, void* stream);
+
 /* ---- readback ---------------------------------------------------------------------------------- */
 
 /* Pinned host memory for the frame ring that feeds the FFmpeg pipe (replaces the arr.copy()/tobytes()

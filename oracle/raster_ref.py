@@ -33,6 +33,8 @@ row intervals ``[r0, r1)`` per pixel column.
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 BG = (13, 13, 18)           # rt_widget.py:829
@@ -308,3 +310,127 @@ def psnr(a: np.ndarray, b: np.ndarray) -> float:
     d = a.astype(np.float64) - b.astype(np.float64)
     mse = float(np.mean(d * d))
     return float('inf') if mse == 0.0 else 10.0 * np.log10(255.0 * 255.0 / mse)
+
+
+# --------------------------------------------------------------------------- Spectrum - Radial (closed stroke + disc)
+#
+# Same coverage rule as above (pixel centre inside the closed outline), evaluated per primitive and per pixel row:
+#   * closed polyline stroke = one rectangle per segment (half-width 1, no caps: the path is closed) + one bevel
+#     triangle per vertex on the outer side of the turn; each primitive is a convex polygon whose intersection with
+#     the row line y = r + 0.5 is an x interval [xmin, xmax]; pixels ceil(xmin - .5) .. floor(xmax - .5) are lit;
+#   * the centre disc (rt_widget.py:1056-1096, QColor(30, 30, 40)) is an even-odd polygon fill sampled at pixel
+#     centres.  The reference fills it through an antialiased clip; antialiased edge blending is NOT reproduced
+#     (documented difference on the one-pixel rim of the disc; Qt coverage is parity-unpinned anyway);
+#   * feather rings (rt_widget.py:1098-1117, only with feather_enabled, which has no UI control) are not rendered.
+# Masks are bit planes uint32[H, ceil(W / 32)], bit (x & 31) of word x >> 5.  All geometry is float64 with the
+# operation order below; the HIP kernels (csrc/radial.hip) use the same order with contraction disabled.
+
+DISC_RGB = (30, 30, 40)     # rt_widget.py:1092/1094
+
+
+def _convex_row_interval(px, py, yc):
+    """x range of the intersection of a convex polygon (vertex lists px, py) with the line y = yc, or None."""
+    n = len(px)
+    xmin, xmax, hit = _BIG, -_BIG, False
+    for e in range(n):
+        x0, y0, x1, y1 = px[e], py[e], px[(e + 1) % n], py[(e + 1) % n]
+        if y0 == y1:
+            if y0 == yc:
+                xmin = min(xmin, x0, x1)
+                xmax = max(xmax, x0, x1)
+                hit = True
+        elif (yc - y0) * (yc - y1) <= 0.0:
+            x = x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0)
+            xmin = min(xmin, x)
+            xmax = max(xmax, x)
+            hit = True
+    return (xmin, xmax) if hit else None
+
+
+def _or_span(mask, r, c0, c1, w):
+    c0 = max(0, int(c0))
+    c1 = min(w, int(c1))
+    for c in range(c0, c1):
+        mask[r, c >> 5] |= np.uint32(1 << (c & 31))
+
+
+def _raster_convex(mask, px, py, w, h):
+    ymin, ymax = min(py), max(py)
+    r0 = max(0, int(math.ceil(ymin - 0.5)))
+    r1 = min(h, int(math.floor(ymax - 0.5)) + 1)
+    for r in range(r0, r1):
+        iv = _convex_row_interval(px, py, r + 0.5)
+        if iv is None:
+            continue
+        xmin, xmax = iv
+        xmin = min(max(xmin, -_BIG), _BIG)
+        xmax = min(max(xmax, -_BIG), _BIG)
+        _or_span(mask, r, math.ceil(xmin - 0.5), math.floor(xmax - 0.5) + 1, w)
+
+
+def stroke_mask_closed(verts, w, h):
+    """Bit plane of a width-2 BevelJoin stroke of the closed polygon through ``verts`` float64[n, 2]."""
+    import math as _m
+    V = np.asarray(verts, dtype=np.float64)
+    n = V.shape[0]
+    mask = np.zeros((h, (w + 31) // 32), dtype=np.uint32)
+    ux = np.zeros(n)
+    uy = np.zeros(n)
+    ok = np.zeros(n, dtype=bool)
+    for s in range(n):                       # segment s: V[s] -> V[(s + 1) % n]
+        ax, ay = V[s]
+        bx, by = V[(s + 1) % n]
+        dx, dy = bx - ax, by - ay
+        ln = _m.sqrt(dx * dx + dy * dy)
+        if ln == 0.0:
+            continue
+        ok[s] = True
+        ux[s], uy[s] = dx / ln, dy / ln
+        nx, ny = -uy[s], ux[s]
+        _raster_convex(mask, [ax + nx, bx + nx, bx - nx, ax - nx], [ay + ny, by + ny, by - ny, ay - ny], w, h)
+    for v in range(n):                       # bevel at V[v] between segments v-1 and v
+        a, b = (v - 1) % n, v
+        if not (ok[a] and ok[b]):
+            continue
+        cr = ux[a] * uy[b] - uy[a] * ux[b]
+        if cr == 0.0:
+            continue
+        sg = -1.0 if cr > 0.0 else 1.0
+        vx, vy = V[v]
+        _raster_convex(mask, [vx, vx + sg * (-uy[a]), vx + sg * (-uy[b])], [vy, vy + sg * ux[a], vy + sg * ux[b]], w, h)
+    return mask
+
+
+def polygon_mask(verts, w, h):
+    """Bit plane of the even-odd fill of the (implicitly closed) polygon ``verts``, sampled at pixel centres."""
+    V = np.asarray(verts, dtype=np.float64)
+    n = V.shape[0]
+    mask = np.zeros((h, (w + 31) // 32), dtype=np.uint32)
+    for r in range(h):
+        yc = r + 0.5
+        xs = []
+        for e in range(n):
+            x0, y0 = V[e]
+            x1, y1 = V[(e + 1) % n]
+            if (y0 <= yc) != (y1 <= yc):
+                xs.append(x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0))
+        xs.sort()
+        for i in range(0, len(xs) - 1, 2):
+            a = min(max(xs[i], -_BIG), _BIG)
+            b = min(max(xs[i + 1], -_BIG), _BIG)
+            _or_span(mask, r, math.ceil(a - 0.5), math.ceil(b - 0.5), w)
+    return mask
+
+
+def unpack_mask(mask, w):
+    bits = ((mask[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool)
+    return bits.reshape(mask.shape[0], -1)[:, :w]
+
+
+def render_radial_frame(path_verts, env_verts, pen_rgb, w, h, bg=BG):
+    """One "Spectrum - Radial" frame: background, radial stroke in the pen colour, centre disc on top."""
+    frame = np.empty((h, w, 3), dtype=np.uint8)
+    frame[:] = np.asarray(bg, dtype=np.uint8)
+    frame[unpack_mask(stroke_mask_closed(path_verts, w, h), w)] = np.asarray(pen_rgb, dtype=np.uint8)
+    frame[unpack_mask(polygon_mask(env_verts, w, h), w)] = np.asarray(DISC_RGB, dtype=np.uint8)
+    return frame

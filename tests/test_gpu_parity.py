@@ -305,7 +305,129 @@ def test_worker_end_to_end_raw_stream(eng, tmp_path, capsys):
     want = _np(FramePipeline(eng, track, "Spectrum - Linear", W, H).render_device()).tobytes()
     assert raw.read_bytes() == want
     # unsupported mode -> exit 1 with an error message, as the reference reports export failures (worker.py:77-79)
-    cfg["mode"] = "Spectrum - Radial"
+    cfg["mode"] = "Waveform - Circular"
     cfgp.write_text(json.dumps(cfg))
     assert worker.main(["worker.py", str(cfgp)]) == 1
     assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["type"] == "error"
+
+
+# ------------------------------------------------------------------ Spectrum - Radial
+
+def _radial_cfg(vs, sens=1.0):
+    from aurora_amd.engine import RadialConfig
+    return RadialConfig.from_view_state(vs, sens)
+
+
+@pytest.mark.parametrize("fixture", ["drawlists_pink_48k_60", "drawlists_sweep_44k1_30", "radialvs_mirror_wavy",
+                                     "radialvs_plain_nosmooth"])
+def test_radial_vertices_vs_reference_paths(eng, fixture):
+    """GPU radial path / disc envelope vs the vertices the reference handed to drawPath / setClipPath."""
+    import json
+    from aurora_amd import _lib
+    g = load_golden(fixture)
+    audio, sr, fps = g["audio"], int(g["sample_rate"]), int(g["fps"])
+    if fixture.startswith("radialvs"):
+        vs, sens = json.loads(str(g["view_state_json"])), float(g["sensitivity"])
+        vs.pop("feather_enabled", None)                      # rings are not rendered; paths do not depend on it
+        sizes = [tuple(int(v) for v in g["size"])]
+        key = lambda wh, f: f"f{f}"
+    else:
+        vs, sens = {}, 1.0
+        sizes = sorted({tuple(int(v) for v in k.split("_")[1].split("x")) for k in g.files if k.startswith("radial_")})
+        key = lambda wh, f: f"radial_{wh[0]}x{wh[1]}_f{f}"
+    cfg = _radial_cfg(vs, sens)
+    track = eng.upload_track(audio, sr, fps)
+    an = eng.analyze(track)
+    sc = eng.scan(an, _lib.ScanParams.defaults(sens))
+    prep = eng.radial_prepare(an, cfg)
+    worst_p = worst_e = 0.0
+    exact = total = 0
+    for wh in sizes:
+        verts, env = eng.radial_vertices(prep, an, sc, wh[0], wh[1], 0, an.n_frames)
+        verts, env = _np(verts), _np(env)
+        for f in range(an.n_frames):
+            k = key(wh, f)
+            if k + "_path" not in g.files:
+                continue
+            want_p, want_e = g[k + "_path"], g[k + "_clip"]
+            assert verts[f].shape == want_p.shape, (k, verts[f].shape, want_p.shape)
+            worst_p = max(worst_p, float(np.max(np.abs(verts[f] - want_p))))
+            worst_e = max(worst_e, float(np.max(np.abs(env[f] - want_e))))
+            exact += int(np.array_equal(verts[f], want_p)) + int(np.array_equal(env[f], want_e))
+            total += 2
+    print(f"{fixture}: max |dx| path {worst_p:.3e} px, envelope {worst_e:.3e} px; {exact}/{total} vertex lists bit-exact")
+    assert total > 0
+    # the path inherits the spectrum's few-ulp float32 difference (normalised bins), hence not bit-exact end to end
+    assert worst_p <= 2e-3 and worst_e <= 2e-3
+
+
+def test_radial_chain_bit_exact_given_same_spectrum(eng):
+    """Stage 1 -> temporal EMA -> stage 2 -> vertices are bit-identical to the oracle when both start from the GPU's
+    own spectrum (default export settings, and a mirrored / rotated / heavily smoothed variant)."""
+    from aurora_amd import synth
+    from oracle import radial_ref as RR
+    sr, fps, W, H = 48000, 60, 1280, 720
+    audio = synth.pink(sr // 2, 2, seed=21)
+    track = eng.upload_track(audio, sr, fps)
+    an = eng.analyze(track)
+    sc = eng.scan(an)
+    ls, energy, phase = _np(an.logspec), _np(sc.energy), _np(sc.phase)
+    for vs in ({}, dict(radial_mirror=True, radial_rotation_deg=33.0, radial_smooth_amount=100,
+                        radial_waveform_smoothness=75, radial_temporal_smoothing=90),
+               dict(radial_smooth_amount=0, radial_waveform_smoothness=0, radial_temporal_smoothing=0)):
+        cfg = _radial_cfg(vs)
+        prep = eng.radial_prepare(an, cfg)
+        verts, env = eng.radial_vertices(prep, an, sc, W, H, 0, an.n_frames)
+        verts, env = _np(verts), _np(env)
+        tr = RR.RadialTrack(RR.RadialParams.from_view_state(vs))
+        for f in range(an.n_frames):
+            want = tr.path(ls[f], float(energy[f]), W, H)
+            assert np.array_equal(verts[f], want), (vs, f, float(np.max(np.abs(verts[f] - want))))
+            want_e = RR.envelope_path(ls[f], float(energy[f]), float(phase[f]), W, H, tr.p)
+            assert np.array_equal(env[f], want_e), (vs, f)
+    # audio-reactive, wavy envelope: device sin / tanh, a few ulp
+    vs = dict(edge_waviness=60, feather_audio_enabled=True, feather_audio_amount=80, radial_mirror=True)
+    cfg = _radial_cfg(vs, 1.3)
+    prep = eng.radial_prepare(an, cfg)
+    _, env = eng.radial_vertices(prep, an, sc, W, H, 0, an.n_frames)
+    p = RR.RadialParams.from_view_state(vs, 1.3)
+    for f in range(an.n_frames):
+        want_e = RR.envelope_path(ls[f], float(energy[f]), float(phase[f]), W, H, p)
+        assert np.allclose(_np(env)[f], want_e, rtol=0, atol=1e-9), f
+
+
+@pytest.mark.parametrize("size", [(640, 368), (1280, 720)])
+def test_radial_raster_bit_exact_given_same_vertices(eng, size):
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    W, H = size
+    sr, fps = 48000, 60
+    audio = synth.pink(6000, 2, seed=8)
+    track = eng.upload_track(audio, sr, fps)
+    pipe = FramePipeline(eng, track, "Spectrum - Radial", W, H,
+                         radial=_radial_cfg(dict(edge_waviness=50, radial_rotation_deg=10.0)))
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    verts, env = eng.radial_vertices(pipe._radial_prep, an, sc, W, H, 0, an.n_frames)
+    verts, env, pen = _np(verts), _np(env), _np(sc.pen_rgb)[:, :3]
+    for f in range(an.n_frames):
+        want = R.render_radial_frame(verts[f], env[f], pen[f], W, H)
+        assert np.array_equal(frames[f], want), (size, f, int(np.sum(frames[f] != want)))
+    assert (frames[1] == np.array(R.DISC_RGB, np.uint8)).all(axis=2).sum() > 0.9 * np.pi * (0.22 * H) ** 2
+
+
+def test_radial_time_shards_byte_identical(eng):
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    import io
+    W, H, sr, fps = 640, 368, 48000, 60
+    audio = synth.pink(sr + 99, 2, seed=12)
+    track = eng.upload_track(audio, sr, fps)
+    F = track.total_frames
+    dev = _np(FramePipeline(eng, track, "Spectrum - Radial", W, H).render_device()).tobytes()
+    for nshards in (1, 3):
+        cuts = [round(i * F / nshards) for i in range(nshards + 1)]
+        buf = io.BytesIO()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            FramePipeline(eng, track, "Spectrum - Radial", W, H, frame_begin=a, frame_end=b, batch_frames=8).run(buf)
+        assert buf.getvalue() == dev, nshards

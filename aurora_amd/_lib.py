@@ -109,7 +109,7 @@ def _declare(lib):
     lib.aur_envelope_vertices.argtypes = [vp, vp, vp, vp, i32, C.POINTER(EnvelopeParams), vp, i32, i32, vp, vp]
     lib.aur_mask_stroke_closed.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.aur_mask_polygon.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
-    lib.aur_raster_planes.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.aur_raster_planes.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp]
     lib.aur_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.aur_host_free.argtypes = [vp]
     lib.aur_readback_async.argtypes = [vp, vp, C.c_size_t, vp, vp]

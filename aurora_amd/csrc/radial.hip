@@ -122,6 +122,17 @@ __global__ __launch_bounds__(256) void radial_ema_kernel(double* __restrict__ va
         prev = vals1[i];
         f = 1;
     }
+    constexpr int U = 16;                     // loads of U frames in flight per thread; the chain itself is serial
+    for (; f + U <= n_frames; f += U) {
+        double cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = vals1[(long)(f + u) * L1 + i];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            prev = alpha * prev + beta * cur[u];
+            vals1[(long)(f + u) * L1 + i] = prev;
+        }
+    }
     for (; f < n_frames; ++f) {
         const double cur = vals1[(long)f * L1 + i];
         prev = alpha * prev + beta * cur;
@@ -332,37 +343,93 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
     }
 }
 
-constexpr int kMaxCross = 64;
-
-// Even-odd fill of the implicitly closed polygon verts[f][nv][2], one thread per pixel row.  Plane zero on entry.
+// Even-odd fill of the implicitly closed polygon verts[f][nv][2].  A thread finds the sorted crossings of one pixel
+// row (vertices staged in LDS; rows outside the polygon's y range have none) and leaves them as pixel spans in LDS;
+// then each wave writes its 64 rows word by word, one coalesced row at a time.  Every word of the plane is written,
+// so the plane needs no clearing.
+constexpr int kPolyMaxV = 384;                // the envelope has 361 vertices
+constexpr int kPolyCross = 32;                 // crossings kept per row (a star-shaped envelope has 2, wavy ones a few)
+__device__ __forceinline__ int span_edge(double x, int W) {
+    const double a = fmin(fmax(x, -kBig), kBig);
+    const int c = (int)ceil(a - 0.5);
+    return c < 0 ? 0 : (c > W ? W : c);
+}
 __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restrict__ verts, int nv, int W, int H,
                                                            int W32, uint32_t* __restrict__ planes) {
+    __shared__ double s_x[kPolyMaxV], s_y[kPolyMaxV];
+    __shared__ double s_lo[2], s_hi[2];
+    __shared__ double s_xs[128][kPolyCross + 1];  // sorted crossings of each row (+1: rows on different banks)
+    __shared__ int s_c[128][kPolyCross + 1];      // the same as clipped pixel-span edges
+    __shared__ int s_cnt[128];
     const int f = blockIdx.y;
-    const int r = blockIdx.x * 128 + threadIdx.x;
-    if (r >= H) return;
     const double* V = verts + (long)f * nv * 2;
-    uint32_t* row = planes + ((long)f * H + r) * W32;
-    const double yc = (double)r + 0.5;
-    double xs[kMaxCross];
-    int m = 0;
-    for (int e = 0; e < nv; ++e) {
-        const int e1 = (e + 1 == nv) ? 0 : e + 1;
-        const double x0 = V[2 * e], y0 = V[2 * e + 1], x1 = V[2 * e1], y1 = V[2 * e1 + 1];
-        if ((y0 <= yc) != (y1 <= yc)) {
-            const double x = x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0);
-            if (m < kMaxCross) {
-                int k = m++;
-                while (k > 0 && xs[k - 1] > x) {      // insertion sort
-                    xs[k] = xs[k - 1];
-                    --k;
-                }
-                xs[k] = x;
-            }
-        }
+    double lo = kBig, hi = -kBig;
+    for (int e = threadIdx.x; e < nv; e += 128) {
+        const double x = V[2 * e], y = V[2 * e + 1];
+        s_x[e] = x;
+        s_y[e] = y;
+        lo = fmin(lo, y);
+        hi = fmax(hi, y);
     }
-    for (int i = 0; i + 1 < m; i += 2) {
-        const double a = fmin(fmax(xs[i], -kBig), kBig), b = fmin(fmax(xs[i + 1], -kBig), kBig);
-        or_span(row, (int)ceil(a - 0.5), (int)ceil(b - 0.5), W);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        lo = fmin(lo, __shfl_xor(lo, m, 64));
+        hi = fmax(hi, __shfl_xor(hi, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    lo = fmin(s_lo[0], s_lo[1]);
+    hi = fmax(s_hi[0], s_hi[1]);
+    const int r = blockIdx.x * 128 + threadIdx.x;
+    const double yc = (double)r + 0.5;
+    int m = 0;
+    if (r < H && yc >= lo && yc <= hi) {
+        double* xs = s_xs[threadIdx.x];
+        double x0 = s_x[nv - 1], y0 = s_y[nv - 1];    // closing edge first: crossings are sorted anyway
+        bool below0 = y0 <= yc;
+#pragma unroll 4
+        for (int e = 0; e < nv; ++e) {
+            const double x1 = s_x[e], y1 = s_y[e];
+            const bool below1 = y1 <= yc;
+            if (below0 != below1) {
+                const double x = x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0);
+                if (m < kPolyCross) {
+                    int k = m++;
+                    while (k > 0 && xs[k - 1] > x) {      // insertion sort
+                        xs[k] = xs[k - 1];
+                        --k;
+                    }
+                    xs[k] = x;
+                }
+            }
+            x0 = x1;
+            y0 = y1;
+            below0 = below1;
+        }
+        m &= ~1;
+        for (int i = 0; i < m; ++i) s_c[threadIdx.x][i] = span_edge(xs[i], W);
+    }
+    s_cnt[threadIdx.x] = m;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x & 64;
+    for (int rr = 0; rr < 64; ++rr) {
+        const int row = blockIdx.x * 128 + wbase + rr;
+        if (row >= H) break;
+        const int cnt = s_cnt[wbase + rr];
+        uint32_t* dst = planes + ((long)f * H + row) * W32;
+        for (int w = lane; w < W32; w += 64) {
+            uint32_t bits = 0;
+            for (int i = 0; i < cnt; i += 2) {            // pixel centre px + 0.5 in [x_i, x_i+1)
+                const int c0 = s_c[wbase + rr][i], c1 = s_c[wbase + rr][i + 1];
+                const int a = c0 > 32 * w ? c0 : 32 * w;
+                const int b = c1 < 32 * w + 32 ? c1 : 32 * w + 32;
+                if (b > a) bits |= (0xffffffffu >> (32 - (b - a))) << (a - 32 * w);
+            }
+            dst[w] = bits;
+        }
     }
 }
 
@@ -386,31 +453,64 @@ __device__ __forceinline__ uint4 pack_rgb16(const uint32_t (&P)[6], int ph) {
     return o;
 }
 
+// One wave owns 64 uint4 columns (up to 12 mask words per row and plane) x 16 rows.  It first pulls the 2 x 16 x 12
+// mask words of its tile with six coalesced loads per lane; a tile without any set bit (most of a frame) is pure
+// background stores, otherwise the words are parked in LDS and every row extracts its 6 pixel bits from there.
+constexpr int kTileWords = 12;
 __global__ __launch_bounds__(256) void raster_fill_planes_kernel(const uint32_t* __restrict__ stroke,
                                                                  const uint32_t* __restrict__ disc,
                                                                  const uint32_t* __restrict__ pen_rgb, int W, int H,
-                                                                 int W32, int nu4, int nchunks,
+                                                                 int W32, int nu4, int nchunks, int disc_static,
                                                                  uint4* __restrict__ frames) {
+    __shared__ uint32_t s_m[4][2][kRowsPerTask][kTileWords];
     const int f = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int task = blockIdx.x * 4 + wave;
     const int chunk = task % nchunks, tile = task / nchunks;
     const int row0 = tile * kRowsPerTask;
-    const int i = chunk * 64 + lane;
-    if (row0 >= H || i >= nu4) return;
+    if (row0 >= H) return;                                   // wave-uniform
     const int row1 = (row0 + kRowsPerTask < H) ? row0 + kRowsPerTask : H;
+    const int wbase = ((1024 * chunk) / 3) >> 5;             // first mask word of the chunk's pixel range
+    uint32_t any = 0;
+    uint32_t* sm = &s_m[wave][0][0][0];
+#pragma unroll
+    for (int k = 0; k < 2 * kRowsPerTask * kTileWords / 64; ++k) {
+        const int idx = lane + 64 * k;
+        const int plane = idx / (kRowsPerTask * kTileWords), rem = idx % (kRowsPerTask * kTileWords);
+        const int r = rem / kTileWords, w = rem % kTileWords;
+        const int gr = (row0 + r < H) ? row0 + r : H - 1;
+        const int gw = (wbase + w < W32) ? wbase + w : W32 - 1;
+        const long fr = (plane && disc_static) ? 0 : f;     // a frame-independent disc is stored once
+        const uint32_t v = (plane ? disc : stroke)[(fr * H + gr) * W32 + gw];
+        sm[idx] = v;
+        any |= v;
+    }
+    const bool busy = __ballot(any != 0) != 0;
+    const int i = chunk * 64 + lane;
+    if (i >= nu4) return;
     const int c0 = (16 * i) / 3, ph = i % 3;
-    const uint32_t pen = pen_rgb[f] & 0x00ffffffu;
-    const int wA = c0 >> 5, sh = c0 & 31;
-    const int wB = (wA + 1 < W32) ? wA + 1 : wA;
     const uint32_t Pbg[6] = {kBg24, kBg24, kBg24, kBg24, kBg24, kBg24};
     const uint4 bgv = pack_rgb16(Pbg, ph);
-    const uint32_t* srow = stroke + ((long)f * H + row0) * W32;
-    const uint32_t* drow = disc + ((long)f * H + row0) * W32;
     uint4* dst = frames + ((long)f * H + row0) * (long)nu4 + i;
+    if (!busy) {
+        for (int row = row0; row < row1; ++row) {
+            *dst = bgv;
+            dst += nu4;
+        }
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t pen = pen_rgb[f] & 0x00ffffffu;
+    const int sh = c0 & 31;
+    const int ia = (c0 >> 5) - wbase;
+    const int ib = (ia + 1 < kTileWords) ? ia + 1 : ia;      // bits of a word past the tile are never needed
     for (int row = row0; row < row1; ++row) {
-        const uint64_t sb = (((uint64_t)srow[wB] << 32) | srow[wA]) >> sh;
-        const uint64_t db = (((uint64_t)drow[wB] << 32) | drow[wA]) >> sh;
+        const uint32_t* ms = sm + (row - row0) * kTileWords;
+        const uint32_t* md = ms + kRowsPerTask * kTileWords;
+        const uint64_t sb = (((uint64_t)ms[ib] << 32) | ms[ia]) >> sh;
+        const uint64_t db = (((uint64_t)md[ib] << 32) | md[ia]) >> sh;
         uint4 o = bgv;
         if (((sb | db) & 0x3fu) != 0) {
             uint32_t P[6];
@@ -421,8 +521,6 @@ __global__ __launch_bounds__(256) void raster_fill_planes_kernel(const uint32_t*
         }
         *dst = o;
         dst += nu4;
-        srow += W32;
-        drow += W32;
     }
 }
 
@@ -536,10 +634,10 @@ extern "C" int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_verti
     if (rc) return rc;
     if ((rc = check_plane_args("aur_mask_polygon", n_frames, n_vertices, W, H))) return rc;
     if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(n_vertices <= kPolyMaxV, "aur_mask_polygon: %d vertices > %d", n_vertices, kPolyMaxV);
     AUR_REQUIRE(d_verts && d_plane, "aur_mask_polygon: null device pointer");
     const int W32 = (W + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
-    AUR_CHECK_HIP(hipMemsetAsync(d_plane, 0, (size_t)n_frames * H * W32 * 4, st));
     hipLaunchKernelGGL(mask_polygon_kernel, dim3((H + 127) / 128, n_frames), dim3(128), 0, st, d_verts, n_vertices, W,
                        H, W32, d_plane);
     AUR_CHECK_HIP(hipGetLastError());
@@ -547,8 +645,8 @@ extern "C" int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_verti
 }
 
 extern "C" int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, const uint32_t* d_disc_plane,
-                                 const uint8_t* d_pen_rgb, int n_frames, int W, int H, uint8_t* d_frames,
-                                 void* stream) {
+                                 int disc_static, const uint8_t* d_pen_rgb, int n_frames, int W, int H,
+                                 uint8_t* d_frames, void* stream) {
     int rc = aur_use_device(ctx);
     if (rc) return rc;
     AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_raster_planes: n_frames %d outside [0, 65535]", n_frames);
@@ -563,7 +661,7 @@ extern "C" int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, c
     const int ntiles = (H + kRowsPerTask - 1) / kRowsPerTask;
     hipLaunchKernelGGL(raster_fill_planes_kernel, dim3((nchunks * ntiles + 3) / 4, n_frames), dim3(256), 0,
                        (hipStream_t)stream, d_stroke_plane, d_disc_plane, reinterpret_cast<const uint32_t*>(d_pen_rgb), W,
-                       H, W32, nu4, nchunks, reinterpret_cast<uint4*>(d_frames));
+                       H, W32, nu4, nchunks, disc_static ? 1 : 0, reinterpret_cast<uint4*>(d_frames));
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -118,6 +118,7 @@ class RadialPrep:
     state: "torch.Tensor"        # float64 [L1]: EMA state after the last frame
     cos_sin: "torch.Tensor"      # float64 [L2 + 1, 2]
     cos_sin360: "torch.Tensor"   # float64 [361, 2]
+    static_disc: dict = None     # (W, H) -> int32 [1, H, W32] disc plane when the envelope is frame-independent
 
 
 def _ptr(t):
@@ -330,7 +331,7 @@ class HipExportEngine:
             self._col2samp[key] = (torch.from_numpy(angle_table(cfg.L2, cfg.radial_rotation_deg)).to(self.device),
                                    torch.from_numpy(angle_table(360, cfg.radial_rotation_deg)).to(self.device))
         cs, cs360 = self._col2samp[key]
-        return RadialPrep(cfg, vals1, st_t, cs, cs360)
+        return RadialPrep(cfg, vals1, st_t, cs, cs360, {})
 
     def carried_radial_state(self, track: Track, frame_begin: int, cfg: RadialConfig, chunk: int = 16384):
         """EMA state of the radial ring in front of ``frame_begin`` (analysis-only pre-pass over [0, frame_begin))."""
@@ -344,46 +345,77 @@ class HipExportEngine:
             f += n
         return state
 
+    def radial_path_vertices(self, prep: RadialPrep, sc: Scan, W: int, H: int, first: int, count: int):
+        """Radial path float64 [count, L2 + 1, 2] of frames first .. first + count."""
+        cfg = prep.cfg
+        verts = self.empty((count, cfg.L2 + 1, 2), self.torch.float64)
+        _lib.check(self.lib.aur_radial_vertices(
+            self.ctx.handle, _ptr(prep.vals1[first:first + count]), _ptr(sc.energy[first:first + count]), count, cfg.L1,
+            int(cfg.radial_smooth_amount), _ptr(prep.cos_sin), W, H, _ptr(verts), cfg.L2, self.stream()),
+            "aur_radial_vertices")
+        return verts
+
     def radial_vertices(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int):
         """(path float64 [count, L2 + 1, 2], envelope float64 [count, 361, 2]) of frames first .. first + count."""
-        torch, cfg = self.torch, prep.cfg
-        h, st = self.ctx.handle, self.stream()
-        L1, L2 = cfg.L1, cfg.L2
-        verts = self.empty((count, L2 + 1, 2), torch.float64)
-        energy = sc.energy[first:first + count]
-        _lib.check(self.lib.aur_radial_vertices(h, _ptr(prep.vals1[first:first + count]), _ptr(energy), count, L1,
-                                                int(cfg.radial_smooth_amount), _ptr(prep.cos_sin), W, H, _ptr(verts),
-                                                L2, st), "aur_radial_vertices")
+        return (self.radial_path_vertices(prep, sc, W, H, first, count),
+                self._envelope(prep, an, sc, W, H, first, count))
+
+    def _envelope(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int):
+        cfg = prep.cfg
         ep = _lib.EnvelopeParams(int(cfg.radial_mirror), int(cfg.edge_waviness), int(cfg.feather_audio_enabled),
                                  int(cfg.feather_audio_amount), float(cfg.feather_sensitivity),
                                  float(cfg.waveform_sensitivity), float(np.deg2rad(cfg.radial_rotation_deg)))
-        env = self.empty((count, 361, 2), torch.float64)
-        _lib.check(self.lib.aur_envelope_vertices(h, _ptr(an.logspec[first:first + count]), _ptr(energy),
-                                                  _ptr(sc.phase[first:first + count]), count, C.byref(ep),
-                                                  _ptr(prep.cos_sin360), W, H, _ptr(env), st), "aur_envelope_vertices")
-        return verts, env
+        env = self.empty((count, 361, 2), self.torch.float64)
+        _lib.check(self.lib.aur_envelope_vertices(
+            self.ctx.handle, _ptr(an.logspec[first:first + count]), _ptr(sc.energy[first:first + count]),
+            _ptr(sc.phase[first:first + count]), count, C.byref(ep), _ptr(prep.cos_sin360), W, H, _ptr(env),
+            self.stream()), "aur_envelope_vertices")
+        return env
+
+    def radial_planes(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int,
+                      planes_out=None):
+        """(stroke planes int32 [count, H, W32], disc planes int32 [count or 1, H, W32], disc_static).
+
+        With the export defaults (edge_waviness 0, audio term off) the disc envelope is the same circle in every
+        frame (rt_widget.py:1038 reduces to r = inner): its plane is rasterised once per frame size and reused."""
+        torch, cfg = self.torch, prep.cfg
+        W32 = (W + 31) // 32
+        h, st = self.ctx.handle, self.stream()
+        if planes_out is None:
+            planes_out = self.empty((2, count, H, W32), torch.int32)
+        verts = self.radial_path_vertices(prep, sc, W, H, first, count)
+        _lib.check(self.lib.aur_mask_stroke_closed(h, _ptr(verts), int(verts.shape[1]), count, W, H,
+                                                   _ptr(planes_out[0]), st), "aur_mask_stroke_closed")
+        static = cfg.edge_waviness == 0 and not (cfg.feather_audio_enabled and cfg.feather_audio_amount > 0)
+        if static:
+            key = (W, H)
+            if key not in prep.static_disc:
+                env = self._envelope(prep, an, sc, W, H, first, 1)
+                plane = self.empty((1, H, W32), torch.int32)
+                _lib.check(self.lib.aur_mask_polygon(h, _ptr(env), 361, 1, W, H, _ptr(plane), st), "aur_mask_polygon")
+                prep.static_disc[key] = plane
+            return planes_out[0], prep.static_disc[key], True
+        env = self._envelope(prep, an, sc, W, H, first, count)
+        _lib.check(self.lib.aur_mask_polygon(h, _ptr(env), 361, count, W, H, _ptr(planes_out[1]), st),
+                   "aur_mask_polygon")
+        return planes_out[0], planes_out[1], False
+
+    def fill_planes(self, planes, pen_rgb, W: int, H: int, out=None):
+        stroke, disc, static = planes
+        count = int(stroke.shape[0])
+        if out is None:
+            out = self.empty((count, H, W, 3), self.torch.uint8)
+        _lib.check(self.lib.aur_raster_planes(self.ctx.handle, _ptr(stroke), _ptr(disc), int(static), _ptr(pen_rgb),
+                                              count, W, H, _ptr(out), self.stream()), "aur_raster_planes")
+        return out
 
     def render_radial(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int = 0,
                       count: int | None = None, out=None, planes_out=None):
         """Frames uint8 [count, H, W, 3] of "Spectrum - Radial" (paint_frame, rt_widget.py:821-852)."""
-        torch = self.torch
         if count is None:
             count = an.n_frames - first
-        verts, env = self.radial_vertices(prep, an, sc, W, H, first, count)
-        W32 = (W + 31) // 32
-        if planes_out is None:
-            planes_out = self.empty((2, count, H, W32), torch.int32)
-        h, st = self.ctx.handle, self.stream()
-        _lib.check(self.lib.aur_mask_stroke_closed(h, _ptr(verts), int(verts.shape[1]), count, W, H,
-                                                   _ptr(planes_out[0]), st), "aur_mask_stroke_closed")
-        _lib.check(self.lib.aur_mask_polygon(h, _ptr(env), 361, count, W, H, _ptr(planes_out[1]), st),
-                   "aur_mask_polygon")
-        if out is None:
-            out = self.empty((count, H, W, 3), torch.uint8)
-        _lib.check(self.lib.aur_raster_planes(h, _ptr(planes_out[0]), _ptr(planes_out[1]),
-                                              _ptr(sc.pen_rgb[first:first + count]), count, W, H, _ptr(out), st),
-                   "aur_raster_planes")
-        return out
+        planes = self.radial_planes(prep, an, sc, W, H, first, count, planes_out)
+        return self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
 
     # ------------------------------------------------------------------ streaming Analyzer step
     def stft_buffer(self, d_buffer, d_prev_mag, d_logspec, d_flux_sum):

@@ -96,7 +96,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from aurora_amd import _lib, sharding, synth
-    from aurora_amd.engine import get_engine, mode_kind
+    from aurora_amd.engine import RadialConfig, get_engine, mode_kind
     from aurora_amd.pipeline import FramePipeline, NullSink
 
     eng = get_engine(local_rank)
@@ -106,11 +106,16 @@ def main():
     track = eng.make_track(audio, sr, fps)
     F = track.total_frames
     kind = mode_kind(args.mode)
-    K = {"spectrum_linear": _lib.K_SPECTRUM, "particles": _lib.K_PARTICLES, "waveform_linear": _lib.K_WAVEFORM}[kind]
+    radial = RadialConfig() if kind == "spectrum_radial" else None
+    K = {"spectrum_linear": _lib.K_SPECTRUM, "particles": _lib.K_PARTICLES, "waveform_linear": _lib.K_WAVEFORM,
+         "spectrum_radial": 0}[kind]
     B = max(1, min(args.batch, F))
     slots = 2
     dev_frames = [eng.empty((B, H, W, 3), torch.uint8) for _ in range(slots)]
-    dev_spans = [eng.empty((B, K, W), torch.int32) for _ in range(slots)]
+    if radial is not None:
+        dev_spans = [eng.empty((2, B, H, (W + 31) // 32), torch.int32) for _ in range(slots)]
+    else:
+        dev_spans = [eng.empty((B, K, W), torch.int32) for _ in range(slots)]
     frame_bytes = W * H * 3
     stft_bytes = 4 * track.channels * min(track.hop, 1024) + 4 * 1025 + 8
 
@@ -123,15 +128,22 @@ def main():
             e1.record()
             ev_stft.append((e0, e1, F))
         sc = eng.scan(an)
+        prep = eng.radial_prepare(an, radial) if radial is not None else None
         done, i = 0, 0
         while done < F:
             n = min(B, F - done)
             s = i % slots
-            spans, _ = eng.spans(kind, an, sc, W, H, done, n, out=dev_spans[s][:n])
+            if radial is not None:
+                planes = eng.radial_planes(prep, an, sc, W, H, done, n, planes_out=dev_spans[s][:, :n])
+            else:
+                spans, _ = eng.spans(kind, an, sc, W, H, done, n, out=dev_spans[s][:n])
             if ev_fill is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            eng.fill(spans, K, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n])
+            if radial is not None:
+                eng.fill_planes(planes, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n])
+            else:
+                eng.fill(spans, K, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n])
             if ev_fill is not None:
                 e1.record()
                 ev_fill.append((e0, e1, n))
@@ -169,14 +181,14 @@ def main():
     roof = kernel_stats(ev_fill, frame_bytes)
     roof_stft = kernel_stats(ev_stft, stft_bytes)
     if roof is not None:
-        roof["kernel"] = f"raster_fill16_kernel<{K}>"
+        roof["kernel"] = "raster_fill_planes_kernel" if radial is not None else f"raster_fill16_kernel<{K}>"
     if roof_stft is not None:
         roof_stft["kernel"] = f"stft_frames_kernel<{track.channels}>"
     try:                                               # per-launch HBM bytes from separate --pmc passes, if collected
         with open(args.traffic_json) as fh:
             tj = json.load(fh)
         key = f"{W}x{H}x{B}"
-        if roof is not None and tj.get("raster_fill", {}).get("config") == key:
+        if roof is not None and radial is None and tj.get("raster_fill", {}).get("config") == key:
             roof["traffic"] = tj["raster_fill"]["hbm_bytes_per_launch"]
         if roof_stft is not None and tj.get("stft", {}).get("frames") == F:
             roof_stft["traffic"] = tj["stft"]["hbm_bytes_per_launch"]

@@ -204,15 +204,17 @@ int aur_envelope_vertices(aur_ctx* ctx, const float* d_logspec, const double* d_
  *   (`p.drawPath(path)` with the width-2 pen, rt_widget.py:975-981);
  * aur_mask_polygon: even-odd fill of the implicitly closed polygon, sampled at pixel centres
  *   (`p.fillPath(path, QColor(30,30,40))` under the clip, rt_widget.py:1056-1096; edge antialiasing not reproduced).
- * Both clear the plane first. */
+ * Both overwrite the whole plane. */
 int aur_mask_stroke_closed(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
                            uint32_t* d_plane, void* stream);
 int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
                      uint32_t* d_plane, void* stream);
 
 /* RGB24 frames of "Spectrum - Radial" (paint_frame, rt_widget.py:821-852): background (13,13,18), stroke plane in the
- * pen colour, disc plane in (30,30,40) on top.  W must be a multiple of 16. */
-int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, const uint32_t* d_disc_plane,
+ * pen colour, disc plane in (30,30,40) on top.  W must be a multiple of 16.  disc_static != 0: d_disc_plane holds ONE
+ * plane [H, ceil(W/32)] used for every frame (the envelope does not depend on the frame when edge_waviness and the
+ * audio term are off, which is the export default). */
+int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, const uint32_t* d_disc_plane, int disc_static,
                       const uint8_t* d_pen_rgb /*[F,4]*/, int n_frames, int W, int H, uint8_t* d_frames, void* stream);
 
 /* ---- readback ---------------------------------------------------------------------------------- */

@@ -414,7 +414,8 @@ def polygon_mask(verts, w, h):
             x1, y1 = V[(e + 1) % n]
             if (y0 <= yc) != (y1 <= yc):
                 xs.append(x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0))
-        xs.sort()
+        xs.sort()       # the kernel keeps the first 32 crossings of a row in edge order; envelopes stay far below that
+        assert len(xs) <= 32
         for i in range(0, len(xs) - 1, 2):
             a = min(max(xs[i], -_BIG), _BIG)
             b = min(max(xs[i + 1], -_BIG), _BIG)

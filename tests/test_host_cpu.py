@@ -161,3 +161,61 @@ def test_synth_shapes():
     b = synth.pink(4800, 2)
     assert a.shape == (4410, 2) and a.dtype == np.float32 and abs(float(np.max(np.abs(a))) - 0.8) < 1e-3
     assert b.shape == (4800, 2) and abs(float(np.max(np.abs(b[:, 0]))) - 0.8) < 1e-6
+
+
+# ------------------------------------------------------------------ radial raster oracle == brute force
+
+def _brute_closed_stroke(V, w, h):
+    """Pixel centre within the closed stroke outline, straight from the rule: rectangles + outer bevel triangles."""
+    img = np.zeros((h, w), dtype=bool)
+    py, px = np.mgrid[0:h, 0:w]
+    cx, cy = px + 0.5, py + 0.5
+    n = len(V)
+    U = []
+    for s in range(n):
+        (x0, y0), (x1, y1) = V[s], V[(s + 1) % n]
+        L = np.hypot(x1 - x0, y1 - y0)
+        ux, uy = (x1 - x0) / L, (y1 - y0) / L
+        U.append((ux, uy))
+        along = (cx - x0) * ux + (cy - y0) * uy
+        across = -(cx - x0) * uy + (cy - y0) * ux
+        img |= (along >= 0) & (along <= L) & (np.abs(across) <= 1.0)
+    for v in range(n):
+        (uxa, uya), (uxb, uyb) = U[(v - 1) % n], U[v]
+        cr = uxa * uyb - uya * uxb
+        if cr == 0:
+            continue
+        sg = -1.0 if cr > 0 else 1.0
+        p0 = np.array(V[v], dtype=float)
+        p1 = p0 + sg * np.array([-uya, uxa])
+        p2 = p0 + sg * np.array([-uyb, uxb])
+
+        def side(a, b):
+            return (b[0] - a[0]) * (cy - a[1]) - (b[1] - a[1]) * (cx - a[0])
+
+        d0, d1, d2 = side(p0, p1), side(p1, p2), side(p2, p0)
+        img |= ((d0 >= 0) & (d1 >= 0) & (d2 >= 0)) | ((d0 <= 0) & (d1 <= 0) & (d2 <= 0))
+    return img
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_closed_stroke_and_polygon_masks_equal_brute_force(seed):
+    rng = np.random.default_rng(seed)
+    w, h, n = 220, 160, 90
+    th = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    r = 45 + 18 * rng.random(n) * (1 + seed)
+    V = np.stack([w / 2 + 0.137 + np.cos(th) * r, h / 2 + 0.291 + np.sin(th) * r], axis=1)
+    got = R.unpack_mask(R.stroke_mask_closed(V, w, h), w)
+    assert np.array_equal(got, _brute_closed_stroke(V, w, h))
+    # even-odd polygon fill vs matplotlib-free winding test (crossing number along +x rays at pixel centres)
+    poly = R.unpack_mask(R.polygon_mask(V, w, h), w)
+    py, px = np.mgrid[0:h, 0:w]
+    cx, cy = px + 0.5, py + 0.5
+    inside = np.zeros((h, w), dtype=bool)
+    for e in range(n):
+        (x0, y0), (x1, y1) = V[e], V[(e + 1) % n]
+        cond = (y0 <= cy) != (y1 <= cy)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            xint = x0 + (cy - y0) * (x1 - x0) / (y1 - y0)
+        inside ^= cond & (xint <= cx)
+    assert np.array_equal(poly, inside)

@@ -1,0 +1,144 @@
+"""BASELINE.json configurations at FULL size on the GPU, checked through size-independent properties and a random
+sample of frames against the oracle (the oracle needs the analysis state from frame 0, so it is run on a prefix and
+on windows re-synchronised through the 2-block halo: a frame's spectrum only depends on its own and the previous
+block).
+
+configs[1]: 4 min 48 kHz stereo pink noise, Spectrum - Linear 1920x1080@60
+configs[2]: 4 min track, Waveform - Linear 3840x2160@60
+configs[3]: 4 min track, particles 1920x1080@60  (+ the feather envelope: Spectrum - Radial, checked separately)
+"""
+import numpy as np
+import pytest
+
+from oracle import analysis_ref as A
+from oracle import raster_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from aurora_amd.engine import get_engine
+    return get_engine(0)
+
+
+@pytest.fixture(scope="module")
+def track4min(eng):
+    from aurora_amd import synth
+    sr, fps = 48000, 60
+    audio = synth.pink_device(sr * 240, 2, 1234, eng.device)
+    track = eng.make_track(audio, sr, fps)
+    an = eng.analyze(track, want_samples=True)
+    sc = eng.scan(an)
+    return track, an, sc
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def test_full_track_analysis_properties(eng, track4min):
+    track, an, sc = track4min
+    F = track.total_frames
+    assert F == 14400 and track.hop == 800
+    ls = an.logspec
+    assert bool((ls >= 0).all()) and bool(ls.isfinite().all())
+    # Parseval on every frame: sum_k c_k |X_k|^2 == N * sum_n (x_n w_n)^2, c = 1 for DC / Nyquist, 2 otherwise
+    import torch
+    mag2 = torch.expm1(ls.double()) ** 2
+    wts = torch.full((1025,), 2.0, dtype=torch.float64, device=ls.device)
+    wts[0] = wts[1024] = 1.0
+    lhs = (mag2 * wts).sum(dim=1)
+    win = torch.from_numpy(eng.ctx.window().astype(np.float64)).to(ls.device)
+    blocks = an.samples.double()
+    prev = torch.cat([torch.zeros(1, 1024, dtype=torch.float64, device=ls.device), blocks[:-1]], dim=0)
+    buf = torch.cat([prev, blocks], dim=1).float() * win.float()          # float32 product, as the reference
+    rhs = 2048.0 * (buf.double() ** 2).sum(dim=1)
+    rel = ((lhs - rhs).abs() / rhs.clamp(min=1e-30)).max().item()
+    print(f"Parseval over {F} frames: max relative deviation {rel:.3e}")
+    assert rel < 5e-6                                                     # float32 magnitudes
+    # zero padding of every block: hop 800 < 1024
+    assert bool((an.samples[:, 800:] == 0).all())
+    # recurrences: phase stays in [0, 2 pi), energy in [0, 1], colours on the gradient
+    ph, en = _np(sc.phase), _np(sc.energy)
+    assert (ph >= 0).all() and (ph < 2 * np.pi).all() and (en >= 0).all() and (en <= 1).all()
+    pen = _np(sc.pen_rgb)
+    r, g = pen[:, 0].astype(np.float64), pen[:, 1].astype(np.float64)
+    # r = int(32 + 223 t), g = int(255 - 255 t), b = 255 (rt_widget.py:496-498): g must fit the t interval r allows
+    g_hi = np.floor(255.0 - 255.0 * (r - 32.0) / 223.0)
+    g_lo = np.floor(255.0 - 255.0 * (r - 31.0) / 223.0)
+    assert ((g >= g_lo) & (g <= g_hi)).all() and (pen[:, 2] == 255).all()
+
+
+def test_full_track_sampled_frames_vs_oracle(eng, track4min):
+    """40 random frames: spectrum within rtol 1e-4 of the oracle, samples / energy exact."""
+    track, an, sc = track4min
+    rng = np.random.default_rng(5)
+    picks = sorted(set([0, 1, 2, track.total_frames - 1] + list(rng.integers(3, track.total_frames - 1, 36))))
+    audio = track.audio
+    hop, pos = track.hop, track.pos_host
+    ls, smp, en = an.logspec, an.samples, sc.energy
+    for f in picks:
+        lo = max(0, f - 1)
+        a0, a1 = int(pos[lo]), min(track.n_samples, int(pos[f]) + hop)
+        seg = _np(audio[a0:a1])
+        ref = A.AnalyzerRef()
+        for g in range(lo, f + 1):
+            s = A.read_frame(seg, int(pos[g]) - a0, hop)
+            spec, _ = ref.compute(s)
+        assert np.array_equal(_np(smp[f]), s)
+        assert float(en[f]) == A.frame_energy(s)
+        assert np.allclose(_np(ls[f]), spec, rtol=1e-4, atol=1e-9), f
+
+
+@pytest.mark.parametrize("mode,size", [("Spectrum - Linear", (1920, 1080)), ("Waveform - Linear", (3840, 2160)),
+                                       ("Particles", (1920, 1080)), ("Spectrum - Radial", (1920, 1080))])
+def test_full_track_render_checksums_and_samples(eng, track4min, mode, size):
+    """Whole 4-minute render in batches: (a) batch size does not change a byte (checksum of checksums),
+    (b) sampled frames equal the oracle rasteriser fed the GPU's analysis values, (c) every pixel is one of the
+    colours the mode can produce."""
+    import torch
+    from aurora_amd.engine import RadialConfig, mode_kind
+    track, an, sc = track4min
+    W, H = size
+    F = track.total_frames
+    radial = mode_kind(mode) == "spectrum_radial"
+    prep = eng.radial_prepare(an, RadialConfig()) if radial else None
+
+    def render(first, count):
+        if radial:
+            return eng.render_radial(prep, an, sc, W, H, first, count)
+        return eng.render(mode, an, sc, W, H, first, count)
+
+    def digest(batch):
+        acc = torch.zeros((), dtype=torch.int64, device=eng.device)
+        mult = torch.arange(1, W * H * 3 // 8 + 1, dtype=torch.int64, device=eng.device)
+        per = []
+        done = 0
+        while done < F:
+            n = min(batch, F - done)
+            fr = render(done, n)
+            words = fr.view(n, -1).view(torch.int64)                 # 8 bytes per word
+            per.append((words * mult).sum(dim=1))                    # wrap-around int64 checksum per frame
+            done += n
+        return torch.cat(per)
+
+    sums_a = digest(96 if W > 2000 else 256)
+    sums_b = digest(37)
+    assert torch.equal(sums_a, sums_b)
+    rng = np.random.default_rng(11)
+    picks = sorted(set([0, F - 1] + list(rng.integers(1, F - 1, 6))))
+    ls, smp = an.logspec, an.samples
+    pen, energy = _np(sc.pen_rgb)[:, :3], _np(sc.energy)
+    for f in picks:
+        got = _np(render(f, 1))[0]
+        if radial:
+            verts, env = eng.radial_vertices(prep, an, sc, W, H, f, 1)
+            want = R.render_radial_frame(_np(verts)[0], _np(env)[0], pen[f], W, H)
+            palette = {tuple(R.BG), tuple(pen[f]), tuple(R.DISC_RGB)}
+        else:
+            want = R.render_frame(mode, _np(smp[f]), _np(ls[f]), float(energy[f]), pen[f], W, H)
+            palette = {tuple(R.BG), tuple(pen[f])}
+        assert np.array_equal(got, want), (mode, f)
+        cols = {tuple(c) for c in np.unique(got.reshape(-1, 3), axis=0)}
+        assert cols <= palette and tuple(R.BG) in cols

@@ -89,17 +89,23 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share a card for rehearsals on a 1-GPU box
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from aurora_amd import _lib, sharding, synth
     from aurora_amd.engine import RadialConfig, get_engine, mode_kind
     from aurora_amd.pipeline import FramePipeline, NullSink
 
-    eng = get_engine(local_rank)
+    eng = get_engine(dev_index)
     sr, fps, W, H = args.sample_rate, args.fps, args.width, args.height
     n_samples = int(round(args.seconds * sr))
     audio = synth.pink_device(n_samples, 2, 1234 + rank, device)      # input resident in HBM before timing
@@ -164,7 +170,7 @@ def main():
         step(ev_fill, ev_stft)
     barrier()
     dt = time.perf_counter() - t0
-    dt = sharding.max_over_ranks(dt, device)
+    dt = sharding.max_over_ranks(dt, device if backend == "nccl" else None)
 
     def kernel_stats(events, bytes_per_frame):
         ms = sum(a.elapsed_time(b) for a, b, _ in events)

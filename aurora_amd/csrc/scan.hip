@@ -7,7 +7,7 @@
 //   _phase      widgets/rt_widget.py:825        (phase + 0.04*(0.5+energy)) % (2*pi)
 //
 // One workgroup (256 threads) per call: the element-wise parts run on all lanes through LDS tiles, the three
-// recurrences run on three lanes of wave 0 at the same time (each is a 2-operation dependent chain per frame).
+// recurrences run on one lane each of three waves at the same time (each is a 2-operation dependent chain per frame).
 #include "common.h"
 
 namespace {
@@ -57,27 +57,50 @@ __global__ __launch_bounds__(256) void scan_frames_kernel(ScanArgs a) {
             s_ph[i] = 0.04 * (0.5 + e);
         }
         __syncthreads();
-        // the three sequential chains, one lane each
-        if (tid < 3) {
-            double s = s_carry[tid];
-            if (tid == 0) {
-                for (int i = 0; i < m; ++i) {
-                    s = amp_a * s + s_bx[i];
-                    s_bx[i] = s;
+        // the three sequential chains, one lane each; LDS reads run U elements ahead of the dependent chain
+        // (lane 0 of waves 0, 1, 2: three SIMDs run the three chains side by side instead of one wave serialising
+        // its divergent lanes)
+        if ((tid & 63) == 0 && tid < 192) {
+            constexpr int U = 8;
+            const int c = tid >> 6;
+            double s = s_carry[c];
+            double* arr = (c == 0) ? s_bx : (c == 1) ? s_bf : s_ph;
+            const double a = (c == 0) ? amp_a : fl_a;
+            int i = 0;
+            if (c < 2) {
+                for (; i + U <= m; i += U) {
+                    double b[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) b[u] = arr[i + u];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        s = a * s + b[u];
+                        arr[i + u] = s;
+                    }
                 }
-            } else if (tid == 1) {
-                for (int i = 0; i < m; ++i) {
-                    s = fl_a * s + s_bf[i];
-                    s_bf[i] = s;
+                for (; i < m; ++i) {
+                    s = a * s + arr[i];
+                    arr[i] = s;
                 }
             } else {
-                for (int i = 0; i < m; ++i) {
-                    s = s + s_ph[i];
-                    if (s >= kTwoPi) s = s - kTwoPi;   // fmod of a value in [0, 2*(2 pi)) is this exact subtraction
-                    s_ph[i] = s;
+                for (; i + U <= m; i += U) {
+                    double b[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) b[u] = arr[i + u];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        s = s + b[u];
+                        if (s >= kTwoPi) s = s - kTwoPi;   // fmod of a value in [0, 2*(2 pi)) is this exact subtraction
+                        arr[i + u] = s;
+                    }
+                }
+                for (; i < m; ++i) {
+                    s = s + arr[i];
+                    if (s >= kTwoPi) s = s - kTwoPi;
+                    arr[i] = s;
                 }
             }
-            s_carry[tid] = s;
+            s_carry[c] = s;
         }
         __syncthreads();
         // element-wise back end: colour ramp with int() truncation, stores

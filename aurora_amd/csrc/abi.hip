@@ -70,6 +70,7 @@ extern "C" int aur_create(int device, aur_ctx** out) {
     ctx->num_cus = prop.multiProcessorCount;
     if (const char* e = getenv("AUR_FILL_ROWS")) ctx->fill_rows = atoi(e);
     if (const char* e = getenv("AUR_FILL_NT")) ctx->fill_nt = atoi(e);
+    if (const char* e = getenv("AUR_FILL_MODE")) ctx->fill_mode = atoi(e);
     if (const char* e = getenv("AUR_STFT_FPW")) ctx->stft_fpw = atoi(e);
     double h_tw[AUR_TW_DOUBLES];
     build_tables(ctx->h_window, h_tw);

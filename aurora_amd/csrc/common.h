@@ -28,6 +28,7 @@ struct aur_ctx {
     // tuning knobs, read once from the environment in aur_create (0 = built-in default)
     int fill_rows;         // AUR_FILL_ROWS: rows per wave task of the fill kernel
     int fill_nt;           // AUR_FILL_NT=1: non-temporal frame stores
+    int fill_mode;         // AUR_FILL_MODE=1: aur_raster_spans_ws / aur_raster_planes use the row-tile kernels (A/B runs)
     int stft_fpw;          // AUR_STFT_FPW: frames per wave of the STFT kernel
 };
 

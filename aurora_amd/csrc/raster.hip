@@ -367,6 +367,149 @@ __global__ __launch_bounds__(256) void raster_fill16_kernel(const uint32_t* __re
     }
 }
 
+// ---- linear fill: one aligned 4 KB piece per workgroup, one store per lane -----------------------------------
+//
+// Measured on MI355X (tools/fill_lab.hip): a pure fill reaches 6.9 TB/s only when every 256-lane workgroup writes ONE
+// 4 KB-aligned 4 KB piece with one 16-byte store per lane and workgroups walk the buffer in address order; 16 rows x
+// 1 KB per wave (raster_fill16_kernel) tops out at 5.6 TB/s because its pieces are neither 1 KB- nor 4 KB-aligned
+// (a 4K row is 11.25 KB) and more than one store per lane costs 5-15 %.  A lane therefore owns exactly one uint4 of
+// the whole batch [F * H * nu4], and what it must know about its six pixel columns comes from ONE 8-byte look-up in a
+// per-frame column summary built by span_summary_kernel (a second, dependent look-up only next to a polyline).
+//
+// Summary of uint4 column `col` of frame f (pixel columns c0 .. c0 + 5, c0 = 16 col / 3):
+//   .x = umin | (umax - umin) << 16   union of the lit rows of the six pixel columns (0: nothing lit)
+//   .y = mask6 | flags                bit c: pixel column c0 + c has a span; kSumUniform: every span of the six columns
+//                                     is the same interval (bars, dots): lit pixels = mask6 inside the union;
+//                                     kSumMerged: each pixel column's spans form one interval, stored in merged[f][x]
+constexpr uint32_t kSumUniform = 1u << 8;
+constexpr uint32_t kSumMerged = 1u << 9;
+
+template <int K>
+__global__ __launch_bounds__(256) void span_summary_kernel(const uint32_t* __restrict__ spans, int W, int nu4,
+                                                           int n_frames, uint2* __restrict__ summary,
+                                                           uint32_t* __restrict__ merged) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_frames * nu4) return;
+    const int f = idx / nu4, col = idx - f * nu4;
+    const int c0 = (16 * col) / 3;
+    const uint32_t* sp = spans + (long)f * K * W + c0;
+    uint32_t umin = 0xffffu, umax = 0u, mask = 0u;
+    uint32_t fa = 0u, fb = 0u;                   // first non-empty interval
+    bool uniform = true, all_merged = true;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        uint32_t a[K], b[K];
+        uint32_t lo = 0xffffu, hi = 0u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t v = sp[(long)k * W + c];
+            a[k] = v & 0xffffu;
+            b[k] = v >> 16;
+            if (b[k] > a[k]) {
+                lo = a[k] < lo ? a[k] : lo;
+                hi = b[k] > hi ? b[k] : hi;
+                if (fb == 0u) {
+                    fa = a[k];
+                    fb = b[k];
+                } else if (a[k] != fa || b[k] != fb) {
+                    uniform = false;
+                }
+            }
+        }
+        uint32_t m = 0u;
+        if (hi > lo) {
+            mask |= 1u << c;
+            umin = lo < umin ? lo : umin;
+            umax = hi > umax ? hi : umax;
+            // contiguous iff growing from `lo` through overlapping / touching intervals reaches `hi`
+            uint32_t reach = lo;
+#pragma unroll
+            for (int pass = 0; pass < K; ++pass)
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (b[k] > a[k] && a[k] <= reach && b[k] > reach) reach = b[k];
+            if (reach == hi) m = lo | (hi << 16);
+            else all_merged = false;
+        }
+        merged[(long)f * W + c0 + c] = m;       // neighbouring uint4 columns share pixel columns: identical values
+    }
+    uint2 s;
+    s.x = umax > umin ? (umin | ((umax - umin) << 16)) : 0u;
+    s.y = mask | (uniform ? kSumUniform : 0u) | (all_merged ? kSumMerged : 0u);
+    summary[idx] = s;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void raster_fill_lin_kernel(const uint32_t* __restrict__ spans,
+                                                              const uint2* __restrict__ summary,
+                                                              const uint32_t* __restrict__ merged,
+                                                              const uint32_t* __restrict__ pen_rgb, int W, int H,
+                                                              int nu4, int upf, float inv_upf, float inv_nu4,
+                                                              int head, unsigned total, uint4* __restrict__ frames) {
+    // g = index of this lane's uint4 in the batch; frames + g is 4 KB aligned for lane 0 of every workgroup
+    const unsigned gi = blockIdx.x * 256u + threadIdx.x;
+    if (gi < (unsigned)head) return;
+    const unsigned g = gi - (unsigned)head;
+    if (g >= total) return;
+    // f = g / upf, row = (g % upf) / nu4 by float reciprocal + one-step fix-up (quotients are small: exact after it)
+    int f = (int)((float)g * inv_upf);
+    int u = (int)(g - (unsigned)f * (unsigned)upf);
+    if (u < 0) {
+        u += upf;
+        --f;
+    } else if (u >= upf) {
+        u -= upf;
+        ++f;
+    }
+    int row = (int)((float)u * inv_nu4);
+    int col = u - row * nu4;
+    if (col < 0) {
+        col += nu4;
+        --row;
+    } else if (col >= nu4) {
+        col -= nu4;
+        ++row;
+    }
+    const uint2 s = summary[f * nu4 + col];
+    const uint32_t pen = pen_rgb[f] & 0x00ffffffu;
+    const int ph = col % 3;                             // (16 col) mod 3
+    // background (13,13,18): dword j of the 16 bytes starts at byte (ph + j) % 3 of the repeating pattern 0d 0d 12
+    constexpr uint32_t D0 = kBg24 | (kBg24 << 24), D1 = (kBg24 >> 8) | (kBg24 << 16), D2 = (kBg24 >> 16) | (kBg24 << 8);
+    uint4 o;
+    o.x = ph == 0 ? D0 : (ph == 1 ? D1 : D2);
+    o.y = ph == 0 ? D1 : (ph == 1 ? D2 : D0);
+    o.z = ph == 0 ? D2 : (ph == 1 ? D0 : D1);
+    o.w = o.x;
+    if (((uint32_t)row - (s.x & 0xffffu)) < (s.x >> 16)) {
+        uint32_t P[6];
+        if (s.y & kSumUniform) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) P[c] = ((s.y >> c) & 1u) ? pen : kBg24;
+        } else if (s.y & kSumMerged) {
+            const uint32_t* m = merged + (long)f * W + (16 * col) / 3;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const uint32_t v = m[c];
+                P[c] = (((uint32_t)row - (v & 0xffffu)) < ((v >> 16) - (v & 0xffffu))) ? pen : kBg24;
+            }
+        } else {
+            const uint32_t* sp = spans + (long)f * K * W + (16 * col) / 3;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                bool lit = false;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t v = sp[(long)k * W + c];
+                    lit |= ((uint32_t)row - (v & 0xffffu)) < ((v >> 16) - (v & 0xffffu));
+                }
+                P[c] = lit ? pen : kBg24;
+            }
+        }
+        o = pack_rgb16(P, ph);
+    }
+    frames[g] = o;
+}
+
 int check_raster_dims(const char* who, int n_frames, int W, int H) {
     AUR_REQUIRE(n_frames >= 0, "%s: n_frames %d < 0", who, n_frames);
     AUR_REQUIRE(W >= 160 && W <= 16384 && H >= 16 && H <= 16384, "%s: frame size %dx%d outside [160..16384]x[16..16384]",
@@ -416,6 +559,63 @@ extern "C" int aur_spans_waveform_linear(aur_ctx* ctx, const float* d_samples, c
     const unsigned gx = (unsigned)((W + kWaveCols - 1) / kWaveCols);
     hipLaunchKernelGGL(spans_waveform_kernel, dim3(gx, n_frames), dim3(256), 0, (hipStream_t)stream, d_samples,
                        d_col2samp, d_energy, W, H, d_spans);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+// Work area of the linear fill: uint2 [F, nu4] column summaries, then uint32 [F, W] merged intervals.
+static size_t raster_work_bytes(int n_frames, int W) {
+    return (size_t)n_frames * (size_t)(W * 3 / 16) * 8 + (size_t)n_frames * (size_t)W * 4;
+}
+
+// Shapes the linear fill takes: 16-byte columns, at least one wave of them per row, 32-bit batch indices.
+static bool raster_lin_ok(int n_frames, int W, int H, const void* d_frames) {
+    if (W % 16 != 0 || ((uintptr_t)d_frames & 15u) != 0) return false;
+    const long upf = (long)(W * 3 / 16) * H;
+    return upf >= 256 && upf < (1L << 26) && (long)n_frames * upf + 256 < (1L << 31);
+}
+
+extern "C" int aur_raster_work_bytes(int n_frames, int W, size_t* out_bytes) {
+    AUR_REQUIRE(out_bytes != nullptr && n_frames >= 0 && W >= 16 && W <= 16384, "aur_raster_work_bytes: bad argument");
+    *out_bytes = raster_work_bytes(n_frames, W);
+    return AUR_OK;
+}
+
+extern "C" int aur_raster_spans_ws(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb, int n_frames,
+                                   int W, int H, uint8_t* d_frames, void* d_work, size_t work_bytes, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_raster_dims("aur_raster_spans_ws", n_frames, W, H))) return rc;
+    if (d_work == nullptr || ctx->fill_mode == 1 || !raster_lin_ok(n_frames, W, H, d_frames))
+        return aur_raster_spans(ctx, d_spans, K, d_pen_rgb, n_frames, W, H, d_frames, stream);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_spans && d_pen_rgb && d_frames, "aur_raster_spans_ws: null device pointer");
+    AUR_REQUIRE(K == 2 || K == 5, "aur_raster_spans_ws: K=%d unsupported (2 or 5)", K);
+    AUR_REQUIRE(work_bytes >= raster_work_bytes(n_frames, W), "aur_raster_spans_ws: work area of %zu bytes, need %zu",
+                work_bytes, raster_work_bytes(n_frames, W));
+    AUR_REQUIRE(((uintptr_t)d_work & 15u) == 0 && ((uintptr_t)d_spans & 3u) == 0 && ((uintptr_t)d_pen_rgb & 3u) == 0,
+                "aur_raster_spans_ws: misaligned device pointer");
+    const int nu4 = W * 3 / 16, upf = nu4 * H;
+    uint2* summary = reinterpret_cast<uint2*>(d_work);
+    uint32_t* merged = reinterpret_cast<uint32_t*>(summary + (size_t)n_frames * nu4);
+    const uint32_t* pen = reinterpret_cast<const uint32_t*>(d_pen_rgb);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned gsum = (unsigned)(((long)n_frames * nu4 + 255) / 256);
+    const int head = (int)(((uintptr_t)d_frames & 4095u) / 16u);       // uint4s between the 4 KB boundary and frame 0
+    const unsigned total = (unsigned)n_frames * (unsigned)upf;
+    const unsigned gfill = (unsigned)(((unsigned long)total + (unsigned)head + 255u) / 256u);
+    uint4* out = reinterpret_cast<uint4*>(d_frames);                   // lane 0 of workgroup b stores at out + 256 b - head
+    if (K == 2) {
+        hipLaunchKernelGGL(span_summary_kernel<2>, dim3(gsum), dim3(256), 0, st, d_spans, W, nu4, n_frames, summary,
+                           merged);
+        hipLaunchKernelGGL(raster_fill_lin_kernel<2>, dim3(gfill), dim3(256), 0, st, d_spans, summary, merged, pen, W, H,
+                           nu4, upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, out);
+    } else {
+        hipLaunchKernelGGL(span_summary_kernel<5>, dim3(gsum), dim3(256), 0, st, d_spans, W, nu4, n_frames, summary,
+                           merged);
+        hipLaunchKernelGGL(raster_fill_lin_kernel<5>, dim3(gfill), dim3(256), 0, st, d_spans, summary, merged, pen, W, H,
+                           nu4, upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, out);
+    }
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -175,6 +175,7 @@ class HipExportEngine:
         self.ctx = _lib.Context(self.device_index)
         self.lib = self.ctx.lib
         self._col2samp = {}
+        self._work = None
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):
@@ -289,11 +290,32 @@ class HipExportEngine:
         _lib.check(rc, f"aur_spans_{kind}")
         return out, K
 
-    def fill(self, spans, K: int, pen_rgb, W: int, H: int, out=None):
+    def raster_work(self, count: int, W: int):
+        """Work area of the linear fill for `count` frames of width W (grown on demand, reused across calls on the
+        engine's stream: launches on one stream are ordered, so the next batch may overwrite it)."""
+        need = C.c_size_t(0)
+        _lib.check(self.lib.aur_raster_work_bytes(int(count), int(W), C.byref(need)), "aur_raster_work_bytes")
+        if self._work is None or self._work.numel() < need.value:
+            self._work = self.empty((max(need.value, 16),), self.torch.uint8)
+        return self._work
+
+    def fill(self, spans, K: int, pen_rgb, W: int, H: int, out=None, work=None):
         torch = self.torch
         count = int(spans.shape[0])
         if out is None:
             out = self.empty((count, H, W, 3), torch.uint8)
+        if work is None:
+            work = self.raster_work(count, W)
+        _lib.check(self.lib.aur_raster_spans_ws(self.ctx.handle, _ptr(spans), K, _ptr(pen_rgb), count, W, H,
+                                                _ptr(out), _ptr(work), work.numel(), self.stream()),
+                   "aur_raster_spans_ws")
+        return out
+
+    def fill_tiles(self, spans, K: int, pen_rgb, W: int, H: int, out=None):
+        """The row-tile fill (no work area): aur_raster_spans."""
+        count = int(spans.shape[0])
+        if out is None:
+            out = self.empty((count, H, W, 3), self.torch.uint8)
         _lib.check(self.lib.aur_raster_spans(self.ctx.handle, _ptr(spans), K, _ptr(pen_rgb), count, W, H,
                                              _ptr(out), self.stream()), "aur_raster_spans")
         return out

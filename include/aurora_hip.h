@@ -157,6 +157,16 @@ int aur_spans_waveform_linear(aur_ctx* ctx, const float* d_samples /*[F,1024]*/,
 int aur_raster_spans(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb /*[F,4]*/,
                      int n_frames, int W, int H, uint8_t* d_frames, void* stream);
 
+/* The same frames through the linear fill (one 4 KB-aligned 4 KB piece of the batch per workgroup, one store per lane:
+ * the store shape that reaches the HBM write ceiling of MI355X).  d_work: device work area of
+ * aur_raster_work_bytes(n_frames, W) bytes, 16-byte aligned, overwritten by every call (per-frame column summaries the
+ * fill looks up instead of re-reading spans).  Falls back to aur_raster_spans when d_work is NULL or the shape does
+ * not suit (W not a multiple of 16, fewer than 256 16-byte columns per frame, batch above 2^31 columns).
+ * Replaces the same reference code as aur_raster_spans; results are byte-identical to it. */
+int aur_raster_work_bytes(int n_frames, int W, size_t* out_bytes);
+int aur_raster_spans_ws(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb /*[F,4]*/,
+                        int n_frames, int W, int H, uint8_t* d_frames, void* d_work, size_t work_bytes, void* stream);
+
 /* ---- "Spectrum - Radial": radial path, centre-disc envelope, bit planes ------------------------------------ */
 
 /* Stage 1 of the radial spectrum (rt_widget.py:938-951): spectrum[:80] / max (float32) -> optional mirror

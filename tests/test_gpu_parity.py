@@ -168,6 +168,59 @@ def test_raster_bit_exact_given_same_analysis(eng, mode, size):
         assert np.array_equal(frames[f], want), (mode, size, f, int(np.sum(frames[f] != want)))
 
 
+@pytest.mark.parametrize("K", [2, 5])
+@pytest.mark.parametrize("size,offset16", [((1280, 720), 0), ((1920, 1080), 5), ((3840, 2160), 0), ((176, 32), 3),
+                                           ((2048, 16), 255)])
+def test_linear_fill_equals_tile_fill(eng, K, size, offset16):
+    """aur_raster_spans_ws (one aligned 4 KB piece per workgroup + column summaries) against aur_raster_spans on random
+    spans: uniform columns, single merged intervals, disjoint intervals in one pixel column (unmergeable), rows at the
+    frame edges, a frame base that is not 4 KB aligned."""
+    import torch
+    W, H = size
+    F = 5
+    rng = np.random.default_rng(W * 31 + K)
+    sp = np.zeros((F, K, W), dtype=np.uint32)
+    for f in range(F):
+        for x in rng.choice(W, size=max(4, W // 6), replace=False):
+            kind = rng.integers(0, 4)
+            r0 = int(rng.integers(0, H))
+            r1 = int(min(H, r0 + rng.integers(1, max(2, H // 2))))
+            if kind == 0:                                   # a 2-px bar: same interval in two planes
+                sp[f, 0, x] = r0 | (r1 << 16)
+                if x > 0:
+                    sp[f, 1, x - 1] = r0 | (r1 << 16)
+            elif kind == 1:                                 # overlapping / touching intervals: mergeable
+                mid = (r0 + r1) // 2
+                sp[f, 0, x] = r0 | (max(mid, r0 + 1) << 16)
+                sp[f, K - 1, x] = min(mid, r1 - 1) | (r1 << 16)
+            elif kind == 2 and r1 - r0 >= 3:                # two disjoint intervals: not mergeable
+                sp[f, 0, x] = r0 | ((r0 + 1) << 16)
+                sp[f, 1, x] = (r1 - 1) | (r1 << 16)
+            else:
+                sp[f, int(rng.integers(0, K)), x] = r0 | (r1 << 16)
+        sp[f, 0, 0] = 0 | (H << 16)                         # full-height first column
+        sp[f, K - 1, W - 1] = (H - 1) | (H << 16)           # last pixel of the frame
+    spans = torch.from_numpy(sp.view(np.int32)).to(eng.device)
+    pen = torch.from_numpy(rng.integers(0, 256, size=(F, 4), dtype=np.uint8)).to(eng.device)
+    pen[:, 3] = 0
+    want = _np(eng.fill_tiles(spans, K, pen, W, H))
+    raw = torch.zeros(F * H * W * 3 + 16 * offset16 + 4096, dtype=torch.uint8, device=eng.device)
+    out = raw[16 * offset16:16 * offset16 + F * H * W * 3].view(F, H, W, 3)
+    eng.fill(spans, K, pen, W, H, out=out)
+    got = _np(out)
+    assert np.array_equal(got, want), int(np.sum(got != want))
+    r = _np(raw)
+    assert not r[:16 * offset16].any() and not r[16 * offset16 + F * H * W * 3:].any()   # nothing outside the batch
+    # and against the definition
+    f = F - 1
+    lit = np.zeros((H, W), dtype=bool)
+    rows = np.arange(H)[:, None]
+    for k in range(K):
+        lit |= (rows >= (sp[f, k] & 0xffff)[None, :]) & (rows < (sp[f, k] >> 16)[None, :])
+    exp = np.where(lit[..., None], _np(pen)[f, :3][None, None, :], np.array([13, 13, 18], dtype=np.uint8))
+    assert np.array_equal(got[f], exp)
+
+
 @pytest.mark.parametrize("fixture", ["drawlists_pink_48k_60", "drawlists_sweep_44k1_30"])
 def test_spans_vs_reference_drawlists(eng, fixture):
     """GPU spans rebuilt from the reference's own draw calls (fixtures) for the same frames."""

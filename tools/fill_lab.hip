@@ -1,0 +1,437 @@
+// Store-pattern laboratory for the frame fill (GPU box):  which shapes of a pure 16-byte-per-lane fill reach the
+// HBM write ceiling on MI355X?  Build: hipcc -O3 --offload-arch=gfx950 tools/fill_lab.hip -o tools/fill_lab
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <utility>
+
+#define CK(x)                                                                 \
+    do {                                                                      \
+        hipError_t e_ = (x);                                                  \
+        if (e_ != hipSuccess) {                                               \
+            printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__);  \
+            exit(1);                                                          \
+        }                                                                     \
+    } while (0)
+
+// linear: block b of T threads writes R pieces of T*16 bytes.  strided=0: pieces b*R..b*R+R-1; strided=1: b + r*grid.
+// rot rotates the piece index inside groups of 8 (moves a piece to another XCD's block).
+template <int T>
+__global__ __launch_bounds__(T) void lin_kernel(uint4* __restrict__ p, long npieces, int R, int strided, int rot,
+                                                uint4 val) {
+    for (int r = 0; r < R; ++r) {
+        long piece = strided ? (long)blockIdx.x + (long)r * gridDim.x : (long)blockIdx.x * R + r;
+        piece = (piece & ~7L) | ((piece + rot) & 7L);
+        if (piece < npieces) p[piece * T + threadIdx.x] = val;
+    }
+}
+
+// the shipped shape: a wave owns 64 uint4 columns x rows_per_task rows of a frame of nu4 uint4 columns x H rows
+__global__ __launch_bounds__(256) void tile_kernel(uint4* __restrict__ p, int nu4, int H, int nchunks,
+                                                   int rows_per_task, uint4 val) {
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int chunk = task % nchunks, tile = task / nchunks;
+    const int row0 = tile * rows_per_task;
+    const int i = chunk * 64 + lane;
+    if (row0 >= H || i >= nu4) return;
+    const int row1 = (row0 + rows_per_task < H) ? row0 + rows_per_task : H;
+    uint4* dst = p + ((long)f * H + row0) * (long)nu4 + i;
+    for (int row = row0; row < row1; ++row) {
+        *dst = val;
+        dst += nu4;
+    }
+}
+
+// linear with a table lookup per store (stands for the per-column span summary of a frame)
+template <int T>
+__global__ __launch_bounds__(T) void lin_lookup_kernel(uint4* __restrict__ p, long npieces, int R,
+                                                       const uint32_t* __restrict__ table, int nu4, uint4 val) {
+    for (int r = 0; r < R; ++r) {
+        const long piece = (long)blockIdx.x * R + r;
+        if (piece >= npieces) return;
+        const long u = piece * T + threadIdx.x;
+        const int col = (int)(u % nu4);
+        const int row = (int)((u / nu4) % 2160);
+        const uint32_t s = table[col];
+        uint4 o = val;
+        if ((uint32_t)row - (s & 0xffffu) < (s >> 16)) o.x = ~o.x;
+        p[u] = o;
+    }
+}
+
+
+// candidate for the shipped kernel: one 4 KB piece per 256-thread block, grid (pieces per frame, frames); a thread
+// stores ONE uint4 after one 4-byte lookup of its column's span summary (umin | ulen << 16).
+__device__ __forceinline__ uint4 bg_pattern(int ph) {
+    // background (13,13,18): dword j of the 16 bytes starts at byte (ph + j) % 3 of the repeating pattern 0d 0d 12
+    const uint32_t D0 = 0x0d120d0du, D1 = 0x0d0d120du, D2 = 0x120d0d12u;
+    const uint32_t a = ph == 0 ? D0 : (ph == 1 ? D1 : D2);
+    const uint32_t b = ph == 0 ? D1 : (ph == 1 ? D2 : D0);
+    const uint32_t c = ph == 0 ? D2 : (ph == 1 ? D0 : D1);
+    return uint4{a, b, c, a};
+}
+__device__ __forceinline__ uint4 pack6(const uint32_t (&P)[6], int ph) {
+    const uint32_t s0 = P[0] | (P[1] << 24), s1 = (P[1] >> 8) | (P[2] << 16), s2 = (P[2] >> 16) | (P[3] << 8);
+    const uint32_t s3 = P[4] | (P[5] << 24), s4 = P[5] >> 8;
+    uint4 o;
+    o.x = __builtin_amdgcn_alignbyte(s1, s0, ph);
+    o.y = __builtin_amdgcn_alignbyte(s2, s1, ph);
+    o.z = __builtin_amdgcn_alignbyte(s3, s2, ph);
+    o.w = __builtin_amdgcn_alignbyte(s4, s3, ph);
+    return o;
+}
+// mode 0: no lookup; 1: summary lookup, lit path = mask form; 2: lit path = six intervals; 3: summary lookup only
+__global__ __launch_bounds__(256) void lin2d_kernel(uint4* __restrict__ p, const uint2* __restrict__ colsum,
+                                                    const uint32_t* __restrict__ iv6, int nu4, int H,
+                                                    int u4_per_frame, float inv_nu4, int mode) {
+    const int f = blockIdx.y;
+    const int u0 = blockIdx.x * 256;
+    int row = (int)((float)u0 * inv_nu4);
+    int col = u0 - row * nu4;
+    if (col < 0) { col += nu4; --row; } else if (col >= nu4) { col -= nu4; ++row; }
+    col += threadIdx.x;
+    while (col >= nu4) { col -= nu4; ++row; }
+    const int u = u0 + threadIdx.x;
+    if (u >= u4_per_frame) return;
+    const int ph = col % 3;
+    uint4 o = bg_pattern(ph);
+    if (mode >= 1) {
+        const uint2 s = colsum[f * nu4 + col];
+        if ((uint32_t)row - (s.x & 0xffffu) < (s.x >> 16)) {
+            const uint32_t pen = 0x00c8ff20u, bg = 0x00120d0du;
+            if (mode == 1) {
+                uint32_t P[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) P[c] = (s.y >> c) & 1u ? pen : bg;
+                o = pack6(P, ph);
+            } else if (mode == 2) {
+                const uint32_t* q = iv6 + ((long)f * nu4 + col) * 6;
+                uint32_t P[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const uint32_t v = q[c];
+                    P[c] = ((uint32_t)row - (v & 0xffffu)) < (v >> 16) ? pen : bg;
+                }
+                o = pack6(P, ph);
+            }
+        }
+    }
+    p[(long)f * u4_per_frame + u] = o;
+}
+
+// mode 0 of lin2d plus (a) NV dependent VALU instructions, (b) one scalar load of NS dwords per wave from a per-frame
+// table, folded into the stored value so nothing is dead
+template <int NV, int NS>
+__global__ __launch_bounds__(256) void budget_kernel(uint4* __restrict__ p, const uint32_t* __restrict__ tbl, int nu4,
+                                                     int u4_per_frame, float inv_nu4) {
+    const int f = blockIdx.y;
+    const int u0 = blockIdx.x * 256;
+    int row = (int)((float)u0 * inv_nu4);
+    int col = u0 - row * nu4;
+    if (col < 0) { col += nu4; --row; } else if (col >= nu4) { col -= nu4; ++row; }
+    col += threadIdx.x;
+    while (col >= nu4) { col -= nu4; ++row; }
+    const int u = u0 + threadIdx.x;
+    if (u >= u4_per_frame) return;
+    const int ph = col % 3;
+    uint4 o = bg_pattern(ph);
+    uint32_t x = (uint32_t)col;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("v_mad_u32_u24 %0, %0, 3, %1" : "+v"(x) : "v"(row));
+    if (NV > 0 && x == 0x12345u) o.y ^= 1u;
+    if (NS > 0) {
+        const uint32_t* t = tbl + f * 128 + ((row >> 4) & 63);     // uniform
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) acc |= t[i];
+        if (acc == 0x12345u) o.z ^= 1u;
+    }
+    p[(long)f * u4_per_frame + u] = o;
+}
+
+// store-first: every lane stores the background at once, then looks its column up and re-stores the 16 bytes only
+// where a span covers the row (same address, same wave: ordered; the line is still in L2)
+template <int NV>
+__global__ __launch_bounds__(256) void store_first_kernel(uint4* __restrict__ p, const uint2* __restrict__ colsum,
+                                                          int nu4, int u4_per_frame, float inv_nu4) {
+    const int f = blockIdx.y;
+    const int u0 = blockIdx.x * 256;
+    int row = (int)((float)u0 * inv_nu4);
+    int col = u0 - row * nu4;
+    if (col < 0) { col += nu4; --row; } else if (col >= nu4) { col -= nu4; ++row; }
+    col += threadIdx.x;
+    while (col >= nu4) { col -= nu4; ++row; }
+    const int u = u0 + threadIdx.x;
+    if (u >= u4_per_frame) return;
+    const uint2 s = colsum[f * nu4 + col];
+    const int ph = col % 3;
+    uint32_t x = (uint32_t)col;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("v_mad_u32_u24 %0, %0, 3, %1" : "+v"(x) : "v"(row));
+    uint4 o = bg_pattern(ph);
+    if (NV > 0 && x == 0x12345u) o.y ^= 1u;
+    uint4* dst = p + (long)f * u4_per_frame + u;
+    *dst = o;
+    if ((uint32_t)row - (s.x & 0xffffu) < (s.x >> 16)) {
+        const uint32_t pen = 0x00c8ff20u, bg = 0x00120d0du;
+        uint32_t P[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) P[c] = (s.y >> c) & 1u ? pen : bg;
+        *dst = pack6(P, ph);
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void writelane(uint32_t& v, uint32_t t) {
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(t), "n"(K));
+}
+template <int N, int... Ks>
+__device__ __forceinline__ void spread(uint32_t& v, const uint32_t (&t)[N], std::integer_sequence<int, Ks...>) {
+    (writelane<Ks>(v, t[Ks]), ...);
+}
+// bars from a per-frame run table read with SCALAR loads only: run n lights pixel columns n*bar_w - 1, n*bar_w over
+// rows [r0, r1) (tbl[f][n] = r0 | r1 << 16, 128 entries per frame, unused = 0).  No vector load on any path.
+template <int NW>
+__global__ __launch_bounds__(256) void runs_kernel(uint4* __restrict__ p, const uint32_t* __restrict__ tbl, int nu4,
+                                                   int H, int u4_per_frame, float inv_nu4, int bar_w, float inv_bar_w,
+                                                   int nruns) {
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u0 = blockIdx.x * 256 + 64 * wave;                 // wave-uniform
+    int row0 = (int)((float)u0 * inv_nu4);
+    int colw = u0 - row0 * nu4;
+    if (colw < 0) { colw += nu4; --row0; } else if (colw >= nu4) { colw -= nu4; ++row0; }
+    if (u0 >= u4_per_frame) return;
+    int col = colw + lane, row = row0;
+    const bool wrapped = col >= nu4;                             // nu4 >= 64: at most one wrap inside a wave
+    if (wrapped) { col -= nu4; ++row; }
+    const int ph = col % 3;
+    uint4 o = bg_pattern(ph);
+    // window of candidate runs for the unwrapped lanes: n in [nA, nA + NW)
+    const int pA = (16 * colw) / 3;
+    int nA = ((int)((float)(pA + 6) * inv_bar_w)) & ~3;          // may be one too large before the fix-up: keep slack
+    nA = nA >= 4 ? nA - 4 : 0;
+    const uint32_t* ta = tbl + f * 128 + nA;
+    uint32_t va = 0, lo_min = 0xffffu;
+    {
+        uint32_t t[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            t[k] = ta[k];
+            const uint32_t a = (t[k] >> 16) > (t[k] & 0xffffu) ? (t[k] & 0xffffu) : 0xffffu;
+            lo_min = a < lo_min ? a : lo_min;
+        }
+        spread(va, t, std::make_integer_sequence<int, NW>{});
+    }
+    const bool wave_wraps = colw + 63 >= nu4;                    // uniform
+    uint32_t vb = 0;
+    if (wave_wraps) {
+        const uint32_t* tb = tbl + f * 128;
+        uint32_t t[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            t[k] = tb[k];
+            const uint32_t a = (t[k] >> 16) > (t[k] & 0xffffu) ? (t[k] & 0xffffu) : 0xffffu;
+            lo_min = a < lo_min ? a : lo_min;
+        }
+        spread(vb, t, std::make_integer_sequence<int, NW>{});
+    }
+    if ((uint32_t)(row0 + 1) >= lo_min) {                         // uniform: some run of the window may reach this row
+        const int c0 = (16 * col) / 3;
+        int n = (int)((float)(c0 + 6) * inv_bar_w);
+        if (n * bar_w > c0 + 6) --n; else if ((n + 1) * bar_w <= c0 + 6) ++n;
+        const int base = wrapped ? 0 : nA;
+        const int idx = n - base;
+        const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_bpermute(idx * 4, (int)va);
+        const uint32_t rb = (uint32_t)__builtin_amdgcn_ds_bpermute(idx * 4, (int)vb);
+        const uint32_t r = wrapped ? rb : ra;
+        const int d = n * bar_w - c0;                            // pixel offset of the run's second column; first = d - 1
+        const bool hit = n < nruns && d >= 0 && d <= 6 && ((uint32_t)row - (r & 0xffffu)) < ((r >> 16) - (r & 0xffffu));
+        if (hit) {
+            const uint32_t mask = ((3u << d) >> 1) & 63u;
+            const uint32_t pen = 0x00c8ff20u, bg = 0x00120d0du;
+            uint32_t P[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) P[c] = (mask >> c) & 1u ? pen : bg;
+            o = pack6(P, ph);
+        }
+    }
+    p[(long)f * u4_per_frame + blockIdx.x * 256 + threadIdx.x] = o;
+}
+
+// lin with the whole buffer shifted by `shift` uint4 (pieces no longer 4 KB aligned)
+__global__ __launch_bounds__(256) void lin_shift_kernel(uint4* __restrict__ p, long npieces, int shift, uint4 val) {
+    const long piece = blockIdx.x;
+    if (piece + 1 < npieces) p[piece * 256 + threadIdx.x + shift] = val;
+}
+
+static uint2* g_colsum;
+int main() {
+    const int F = 128, H = 2160, W = 3840;
+    const long bytes = (long)F * H * W * 3;
+    uint4* buf[2];
+    CK(hipMalloc(&buf[0], bytes));
+    CK(hipMalloc(&buf[1], bytes));
+    uint32_t* table;
+    CK(hipMalloc(&table, 4096));
+    CK(hipMemset(table, 0, 4096));
+    const uint4 val = {0x0d0d120du, 0x120d0d12u, 0x0d120d0du, 0x0d0d120du};
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    auto run = [&](const char* name, std::function<void(uint4*)> fn) {
+        for (int i = 0; i < 3; ++i) fn(buf[i & 1]);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        const int n = 10;
+        for (int i = 0; i < n; ++i) fn(buf[i & 1]);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= n;
+        printf("%-46s %.4f ms  %6.0f GB/s\n", name, ms, bytes / ms / 1e6);
+        fflush(stdout);
+    };
+    char name[128];
+    run("hipMemsetAsync", [&](uint4* p) { CK(hipMemsetAsync(p, 0x0d, bytes)); });
+    for (int T : {128, 256})
+        for (int R : {1, 2})
+            for (int strided : {0, 1}) {
+                if (R == 1 && strided) continue;
+                const long np = bytes / (16L * T);
+                const unsigned g = (unsigned)((np + R - 1) / R);
+                snprintf(name, sizeof name, "lin T=%d R=%d %s", T, R, strided ? "grid-strided" : "consecutive");
+                run(name, [&](uint4* p) {
+                    if (T == 128) lin_kernel<128><<<g, 128>>>(p, np, R, strided, 0, val);
+                    if (T == 256) lin_kernel<256><<<g, 256>>>(p, np, R, strided, 0, val);
+                    if (T == 512) lin_kernel<512><<<g, 512>>>(p, np, R, strided, 0, val);
+                    if (T == 1024) lin_kernel<1024><<<g, 1024>>>(p, np, R, strided, 0, val);
+                });
+            }
+    for (int rot : {1, 3, 4}) {
+        const long np = bytes / (16L * 256);
+        snprintf(name, sizeof name, "lin T=256 R=1 rot=%d", rot);
+        run(name, [&](uint4* p) { lin_kernel<256><<<(unsigned)np, 256>>>(p, np, 1, 0, rot, val); });
+    }
+    for (int rpt : {1, 2, 4, 8, 16, 48}) {
+        const int nu4 = W * 3 / 16, nchunks = (nu4 + 63) / 64, ntiles = (H + rpt - 1) / rpt;
+        snprintf(name, sizeof name, "tile 64 cols x %d rows", rpt);
+        run(name, [&](uint4* p) {
+            tile_kernel<<<dim3((nchunks * ntiles + 3) / 4, F), 256>>>(p, nu4, H, nchunks, rpt, val);
+        });
+    }
+    for (int R : {1, 2, 4}) {
+        const long np = bytes / (16L * 256);
+        snprintf(name, sizeof name, "lin+lookup T=256 R=%d", R);
+        run(name, [&](uint4* p) {
+            lin_lookup_kernel<256><<<(unsigned)((np + R - 1) / R), 256>>>(p, np, R, table, W * 3 / 16, val);
+        });
+    }
+
+    {   // realistic candidate
+        const int nu4 = W * 3 / 16, upf = nu4 * H;
+        uint2* colsum;
+        uint32_t* iv6;
+        CK(hipMalloc(&colsum, (size_t)F * nu4 * 8));
+        CK(hipMalloc(&iv6, (size_t)F * nu4 * 24));
+        uint32_t* hs = (uint32_t*)calloc((size_t)F * W, 4);       // one merged interval per pixel column: lo | len << 16
+        uint2* hc = (uint2*)calloc((size_t)F * nu4, 8);
+        uint32_t* hi = (uint32_t*)calloc((size_t)F * nu4 * 6, 4);
+        for (int f = 0; f < F; ++f) {
+            for (int i = 0; i < 80; ++i) {
+                const int x0 = i * 48;
+                const uint32_t lo = 300u + 13u * i + f;
+                const uint32_t v = lo | ((2156u - lo) << 16);
+                hs[(size_t)f * W + x0] = v;
+                if (x0 > 0) hs[(size_t)f * W + x0 - 1] = v;
+            }
+            for (int col = 0; col < nu4; ++col) {
+                uint32_t mn = 0xffff, mx = 0, mask = 0;
+                for (int c = 0; c < 6; ++c) {
+                    const int x = 16 * col / 3 + c;
+                    if (x >= W) continue;
+                    const uint32_t v = hs[(size_t)f * W + x];
+                    hi[((size_t)f * nu4 + col) * 6 + c] = v;
+                    const uint32_t a = v & 0xffff, b = a + (v >> 16);
+                    if (b > a) { if (a < mn) mn = a; if (b > mx) mx = b; mask |= 1u << c; }
+                }
+                hc[(size_t)f * nu4 + col] = uint2{mx > mn ? (mn | ((mx - mn) << 16)) : 0u, mask};
+            }
+        }
+        CK(hipMemcpy(iv6, hi, (size_t)F * nu4 * 24, hipMemcpyHostToDevice));
+        CK(hipMemcpy(colsum, hc, (size_t)F * nu4 * 8, hipMemcpyHostToDevice));
+        g_colsum = colsum;
+        for (int rep = 0; rep < 2; ++rep)
+            for (int mode : {0, 3, 1, 2}) {
+                snprintf(name, sizeof name, "lin2d mode=%d (0 none, 3 lookup, 1 mask, 2 six iv)", mode);
+                run(name, [&](uint4* p) {
+                    lin2d_kernel<<<dim3((upf + 255) / 256, F), 256>>>(p, colsum, iv6, nu4, H, upf, 1.0f / nu4, mode);
+                });
+            }
+    }
+    {   // runs table + scalar loads, checked against mode 1 of lin2d on frame 5
+        const int nu4 = W * 3 / 16, upf = nu4 * H;
+        uint32_t* tbl;
+        CK(hipMalloc(&tbl, (size_t)F * 128 * 4 + 256));
+        uint32_t* ht = (uint32_t*)calloc((size_t)F * 128 + 64, 4);
+        for (int f = 0; f < F; ++f)
+            for (int i = 0; i < 80; ++i) ht[(size_t)f * 128 + i] = (300u + 13u * i + f) | (2156u << 16);
+        CK(hipMemcpy(tbl, ht, (size_t)F * 128 * 4 + 256, hipMemcpyHostToDevice));
+        for (int rep = 0; rep < 2; ++rep)
+            run("runs table via s_load, NW=16", [&](uint4* p) {
+                runs_kernel<16><<<dim3((upf + 255) / 256, F), 256>>>(p, tbl, nu4, H, upf, 1.0f / nu4, 48, 1.0f / 48, 80);
+            });
+        CK(hipDeviceSynchronize());
+        const size_t fb = (size_t)upf * 16;
+        unsigned char* h1 = (unsigned char*)malloc(fb);
+        unsigned char* h2 = (unsigned char*)malloc(fb);
+        // bar 0 at x0 = 0 has only its second column on screen: lin2d's synthetic spans agree (x0 - 1 skipped)
+        runs_kernel<16><<<dim3((upf + 255) / 256, F), 256>>>(buf[0], tbl, nu4, H, upf, 1.0f / nu4, 48, 1.0f / 48, 80);
+        CK(hipMemcpy(h1, (char*)buf[0] + 5 * fb, fb, hipMemcpyDeviceToHost));
+        lin2d_kernel<<<dim3((upf + 255) / 256, F), 256>>>(buf[1], g_colsum, nullptr, nu4, H, upf, 1.0f / nu4, 1);
+        CK(hipMemcpy(h2, (char*)buf[1] + 5 * fb, fb, hipMemcpyDeviceToHost));
+        long diff = 0, lit = 0;
+        for (size_t i = 0; i < fb; ++i) { diff += h1[i] != h2[i]; lit += h1[i] == 0xc8; }
+        printf("runs vs lin2d mask: %ld differing bytes, %ld lit pixels\n", diff, lit);
+    }
+    {
+        const int nu4 = W * 3 / 16, upf = nu4 * H;
+        uint32_t* tbl;
+        CK(hipMalloc(&tbl, (size_t)F * 128 * 4 + 1024));
+        CK(hipMemset(tbl, 0, (size_t)F * 128 * 4 + 1024));
+        const dim3 g((upf + 255) / 256, F);
+#define BUD(NV, NS) run("budget NV=" #NV " NS=" #NS, [&](uint4* p) { budget_kernel<NV, NS><<<g, 256>>>(p, tbl, nu4, upf, 1.0f / nu4); })
+        BUD(0, 0); BUD(16, 0); BUD(32, 0); BUD(64, 0); BUD(96, 0); BUD(128, 0); BUD(0, 1); BUD(0, 4); BUD(0, 16); BUD(32, 4); BUD(0, 0);
+    }
+    {
+        const int nu4 = W * 3 / 16, upf = nu4 * H;
+        const dim3 g((upf + 255) / 256, F);
+        for (int rep = 0; rep < 2; ++rep) {
+            run("store-first NV=0", [&](uint4* p) { store_first_kernel<0><<<g, 256>>>(p, g_colsum, nu4, upf, 1.0f / nu4); });
+            run("store-first NV=16", [&](uint4* p) { store_first_kernel<16><<<g, 256>>>(p, g_colsum, nu4, upf, 1.0f / nu4); });
+        }
+        CK(hipDeviceSynchronize());
+        const size_t fb = (size_t)upf * 16;
+        unsigned char* h1 = (unsigned char*)malloc(fb);
+        unsigned char* h2 = (unsigned char*)malloc(fb);
+        store_first_kernel<0><<<g, 256>>>(buf[0], g_colsum, nu4, upf, 1.0f / nu4);
+        CK(hipMemcpy(h1, (char*)buf[0] + 5 * fb, fb, hipMemcpyDeviceToHost));
+        lin2d_kernel<<<g, 256>>>(buf[1], g_colsum, nullptr, nu4, H, upf, 1.0f / nu4, 1);
+        CK(hipMemcpy(h2, (char*)buf[1] + 5 * fb, fb, hipMemcpyDeviceToHost));
+        long diff = 0;
+        for (size_t i = 0; i < fb; ++i) diff += h1[i] != h2[i];
+        printf("store-first vs lin2d mask: %ld differing bytes\n", diff);
+    }
+    for (int shift : {0, 16, 64, 128}) {
+        const long np = bytes / (16L * 256);
+        snprintf(name, sizeof name, "lin T=256 R=1 shifted by %d B", shift * 16);
+        run(name, [&](uint4* p) { lin_shift_kernel<<<(unsigned)np, 256>>>(p, np, shift, val); });
+    }
+    return 0;
+}

@@ -581,8 +581,35 @@ extern "C" int aur_raster_work_bytes(int n_frames, int W, size_t* out_bytes) {
     return AUR_OK;
 }
 
+extern "C" int aur_span_summary(aur_ctx* ctx, const uint32_t* d_spans, int K, int n_frames, int W, int H, void* d_work,
+                                size_t work_bytes, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_raster_dims("aur_span_summary", n_frames, W, H))) return rc;
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_spans && d_work, "aur_span_summary: null device pointer");
+    AUR_REQUIRE(K == 2 || K == 5, "aur_span_summary: K=%d unsupported (2 or 5)", K);
+    AUR_REQUIRE(W % 16 == 0, "aur_span_summary: width %d must be a multiple of 16", W);
+    AUR_REQUIRE(work_bytes >= raster_work_bytes(n_frames, W), "aur_span_summary: work area of %zu bytes, need %zu",
+                work_bytes, raster_work_bytes(n_frames, W));
+    AUR_REQUIRE(((uintptr_t)d_work & 15u) == 0 && ((uintptr_t)d_spans & 3u) == 0, "aur_span_summary: misaligned pointer");
+    const int nu4 = W * 3 / 16;
+    uint2* summary = reinterpret_cast<uint2*>(d_work);
+    uint32_t* merged = reinterpret_cast<uint32_t*>(summary + (size_t)n_frames * nu4);
+    const unsigned g = (unsigned)(((long)n_frames * nu4 + 255) / 256);
+    if (K == 2)
+        hipLaunchKernelGGL(span_summary_kernel<2>, dim3(g), dim3(256), 0, (hipStream_t)stream, d_spans, W, nu4, n_frames,
+                           summary, merged);
+    else
+        hipLaunchKernelGGL(span_summary_kernel<5>, dim3(g), dim3(256), 0, (hipStream_t)stream, d_spans, W, nu4, n_frames,
+                           summary, merged);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
 extern "C" int aur_raster_spans_ws(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb, int n_frames,
-                                   int W, int H, uint8_t* d_frames, void* d_work, size_t work_bytes, void* stream) {
+                                   int W, int H, uint8_t* d_frames, void* d_work, size_t work_bytes, int work_ready,
+                                   void* stream) {
     int rc = aur_use_device(ctx);
     if (rc) return rc;
     if ((rc = check_raster_dims("aur_raster_spans_ws", n_frames, W, H))) return rc;
@@ -591,31 +618,28 @@ extern "C" int aur_raster_spans_ws(aur_ctx* ctx, const uint32_t* d_spans, int K,
     if (n_frames == 0) return AUR_OK;
     AUR_REQUIRE(d_spans && d_pen_rgb && d_frames, "aur_raster_spans_ws: null device pointer");
     AUR_REQUIRE(K == 2 || K == 5, "aur_raster_spans_ws: K=%d unsupported (2 or 5)", K);
-    AUR_REQUIRE(work_bytes >= raster_work_bytes(n_frames, W), "aur_raster_spans_ws: work area of %zu bytes, need %zu",
-                work_bytes, raster_work_bytes(n_frames, W));
-    AUR_REQUIRE(((uintptr_t)d_work & 15u) == 0 && ((uintptr_t)d_spans & 3u) == 0 && ((uintptr_t)d_pen_rgb & 3u) == 0,
-                "aur_raster_spans_ws: misaligned device pointer");
+    AUR_REQUIRE(((uintptr_t)d_pen_rgb & 3u) == 0, "aur_raster_spans_ws: misaligned device pointer");
+    if (!work_ready) {
+        if ((rc = aur_span_summary(ctx, d_spans, K, n_frames, W, H, d_work, work_bytes, stream))) return rc;
+    } else {
+        AUR_REQUIRE(work_bytes >= raster_work_bytes(n_frames, W) && ((uintptr_t)d_work & 15u) == 0,
+                    "aur_raster_spans_ws: work area too small or misaligned");
+    }
     const int nu4 = W * 3 / 16, upf = nu4 * H;
-    uint2* summary = reinterpret_cast<uint2*>(d_work);
-    uint32_t* merged = reinterpret_cast<uint32_t*>(summary + (size_t)n_frames * nu4);
+    const uint2* summary = reinterpret_cast<const uint2*>(d_work);
+    const uint32_t* merged = reinterpret_cast<const uint32_t*>(summary + (size_t)n_frames * nu4);
     const uint32_t* pen = reinterpret_cast<const uint32_t*>(d_pen_rgb);
     hipStream_t st = (hipStream_t)stream;
-    const unsigned gsum = (unsigned)(((long)n_frames * nu4 + 255) / 256);
     const int head = (int)(((uintptr_t)d_frames & 4095u) / 16u);       // uint4s between the 4 KB boundary and frame 0
     const unsigned total = (unsigned)n_frames * (unsigned)upf;
     const unsigned gfill = (unsigned)(((unsigned long)total + (unsigned)head + 255u) / 256u);
     uint4* out = reinterpret_cast<uint4*>(d_frames);                   // lane 0 of workgroup b stores at out + 256 b - head
-    if (K == 2) {
-        hipLaunchKernelGGL(span_summary_kernel<2>, dim3(gsum), dim3(256), 0, st, d_spans, W, nu4, n_frames, summary,
-                           merged);
+    if (K == 2)
         hipLaunchKernelGGL(raster_fill_lin_kernel<2>, dim3(gfill), dim3(256), 0, st, d_spans, summary, merged, pen, W, H,
                            nu4, upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, out);
-    } else {
-        hipLaunchKernelGGL(span_summary_kernel<5>, dim3(gsum), dim3(256), 0, st, d_spans, W, nu4, n_frames, summary,
-                           merged);
+    else
         hipLaunchKernelGGL(raster_fill_lin_kernel<5>, dim3(gfill), dim3(256), 0, st, d_spans, summary, merged, pen, W, H,
                            nu4, upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, out);
-    }
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -127,63 +127,74 @@ struct __attribute__((aligned(4))) f2a4 {
 
 // One 1024-sample analysis block of frame `fi` (exporter.py:230-237) in the lane layout of the FFT:
 // blk[2jj], blk[2jj+1] = samples[2*lane + 128*jj], samples[2*lane + 128*jj + 1].
-// Frames whose whole 1024-sample read window lies inside the track (all but the last one or two) take a
-// branch-free path: eight unconditional 16-byte loads issued back to back, zero padding by select.
+// Two phases, so that the loads can fly while another frame is being transformed: issue_block requests the raw
+// interleaved samples, mix_block (mono mean + zero padding) is the first thing that waits for them.
+// Frames whose whole 1024-sample read window lies inside the track (all but the last one or two) take eight
+// unconditional 16-byte loads issued back to back; the last frames clamp every sample index to the track instead.
+// Zero padding (samples >= nvalid) is a select against r = nvalid - 2*lane, so nothing per-jj stays in registers.
+template <int C>
+struct RawBlock {
+    float q[8][2 * C];   // jj -> two consecutive samples (C channels each) starting at sample min(s, n_samp - 2)
+    int r;               // sample 128*jj (+1) of this lane is inside the read window iff 128*jj (+1) < r
+    int shifted;         // bit jj: the pair was clamped one sample down (s == n_samp - 1): sample s is its second half
+};
+
+// Branch-free: eight unconditional loads of two samples each (16 bytes for stereo).  A pair that would run past
+// the end of the track is moved down by one sample (`shifted`; its second sample is then outside the read window
+// anyway), a pair entirely outside reads the last two samples and is dropped by the window test; frames before the
+// track start (fi < 0: Analyzer.buffer is zero, analysis.py:14) read frame 0's block with an empty window.
+// No control flow joins behind the loads, so nothing touches the data before mix_block.  Needs n_samp >= 2.
+template <int C>
+__device__ __forceinline__ void issue_block(const float* __restrict__ audio, long n_samp,
+                                            const long* __restrict__ pos, long fi, int hop, int lane,
+                                            RawBlock<C>& raw) {
+    const long p = pos[fi < 0 ? 0 : fi];
+    long nv = n_samp - p;
+    if (nv > hop) nv = hop;
+    if (nv > AUR_BLOCK) nv = AUR_BLOCK;
+    if (fi < 0) nv = 0;
+    raw.r = (int)nv - 2 * lane;
+    raw.shifted = 0;
+    const long last2 = n_samp - 2;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const long i0 = p + 2 * lane + 128 * jj;
+        const long ic = i0 < last2 ? i0 : last2;
+        if (i0 == last2 + 1) raw.shifted |= 1 << jj;
+        if (C == 2) {
+            const f4a8 q = *reinterpret_cast<const f4a8*>(audio + ic * 2);   // (L0, R0, L1, R1)
+            raw.q[jj][0] = q.x;
+            raw.q[jj][1] = q.y;
+            raw.q[jj][2 * C - 2] = q.z;
+            raw.q[jj][2 * C - 1] = q.w;
+        } else {
+            const f2a4 q = *reinterpret_cast<const f2a4*>(audio + ic);
+            raw.q[jj][0] = q.x;
+            raw.q[jj][2 * C - 1] = q.y;
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void mix_block(const RawBlock<C>& raw, float (&blk)[16]) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        // y.mean(axis=1) in float32: (L + R) rounded, then * 0.5 (exporter.py:234)
+        const float a = (C == 2) ? (raw.q[jj][0] + raw.q[jj][1]) * 0.5f : raw.q[jj][0];
+        const float b = (C == 2) ? (raw.q[jj][2 * C - 2] + raw.q[jj][2 * C - 1]) * 0.5f : raw.q[jj][2 * C - 1];
+        const float m0 = ((raw.shifted >> jj) & 1) ? b : a;
+        blk[2 * jj] = (128 * jj < raw.r) ? m0 : 0.0f;
+        blk[2 * jj + 1] = (128 * jj + 1 < raw.r) ? b : 0.0f;
+    }
+}
+
 template <int C>
 __device__ __forceinline__ void load_block(const float* __restrict__ audio, long n_samp,
                                            const long* __restrict__ pos, long fi, int hop, int lane,
                                            float (&blk)[16]) {
-    if (fi < 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) blk[i] = 0.0f;
-        return;
-    }
-    const long p = pos[fi];
-    long nv = n_samp - p;
-    if (nv > hop) nv = hop;
-    if (nv > AUR_BLOCK) nv = AUR_BLOCK;
-    const int nvalid = (int)nv;
-    if (p + AUR_BLOCK <= n_samp) {           // wave-uniform
-        if (C == 2) {
-            const f4a8* src = reinterpret_cast<const f4a8*>(audio + (p + 2 * lane) * 2);
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const f4a8 q = src[64 * jj];                         // (L0, R0, L1, R1) of samples s, s + 1
-                const int s = 2 * lane + 128 * jj;
-                const float m0 = (q.x + q.y) * 0.5f;                 // y.mean(axis=1), exporter.py:234
-                const float m1 = (q.z + q.w) * 0.5f;
-                blk[2 * jj] = (s < nvalid) ? m0 : 0.0f;
-                blk[2 * jj + 1] = (s + 1 < nvalid) ? m1 : 0.0f;
-            }
-        } else {
-            const f2a4* src = reinterpret_cast<const f2a4*>(audio + (p + 2 * lane));
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const f2a4 q = src[64 * jj];
-                const int s = 2 * lane + 128 * jj;
-                blk[2 * jj] = (s < nvalid) ? q.x : 0.0f;
-                blk[2 * jj + 1] = (s + 1 < nvalid) ? q.y : 0.0f;
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) blk[i] = 0.0f;
-#pragma unroll 1
-    for (int jj = 0; jj < 8; ++jj) {         // end of track: guarded scalar loads
-        const int s = 2 * lane + 128 * jj;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (s + t < nvalid) {
-                const float* src = audio + (p + s + t) * C;
-                const float m = (C == 2) ? (src[0] + src[1]) * 0.5f : src[0];
-                // blk index is a compile-time constant only under full unrolling; select instead
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (k == jj) blk[2 * k + t] = m;
-            }
-        }
-    }
+    RawBlock<C> raw;
+    issue_block<C>(audio, n_samp, pos, fi, hop, lane, raw);
+    mix_block<C>(raw, blk);
 }
 
 struct Tables {
@@ -304,18 +315,20 @@ __device__ __forceinline__ void fft_packed(const float (&prv)[16], const float (
 // register of v[] that holds Z[lane + 64 j] after fft_packed
 __device__ __forceinline__ constexpr int zreg(int j) { return 4 * (j & 3) + (j >> 2); }
 
-// |X| in float32 from |X|^2 in float64: v_sqrt_f64 (good to 2^-23 relative over the whole float64 range, so no
-// scaling and no underflow for leakage bins) rounded once to float32: within 1.5 ulp of the exact magnitude.
-__device__ __forceinline__ float mag_from_sq(double m2) { return (float)__builtin_amdgcn_sqrt(m2); }
+// |X| in float32 from |X|^2 in float64: |X|^2 rounded to float32 (relative 2^-24; never outside the float32 range
+// for audio in [-1, 1]: |X| <= 2048, and leakage bins stop at the ~1e-7 rounding noise of the float32 window
+// product) and v_sqrt_f32 (1 ulp): within 1.5 ulp of the exact magnitude at a quarter of v_sqrt_f64's cost.
+__device__ __forceinline__ float mag_from_sq(double m2) { return __builtin_amdgcn_sqrtf((float)m2); }
 
-// log1p for x >= 0 in float32 (the contract is rtol 1e-4; np.log1p is within 1 ulp; this is within ~3 ulp):
-// ln2 * log2(u) + c / u with u = fl(1 + x) and c = x - (u - 1) the rounding error of u.  v_log_f32 is
-// relatively accurate next to 1 (measured over the whole range by tests/test_gpu_parity.py::test_log1p_probe),
-// and for u == 1 the result is c = x exactly.
+// log1p for x >= 0 in float32 (the contract is rtol 1e-4; np.log1p is within 1 ulp; this is within ~4 ulp):
+// ln2 * log2(u) + c / u with u = fl(1 + x) and c = x - (u - 1) the rounding error of u.  c / u only matters next to
+// u = 1 (it is below 2^-24 of the result once u >= 2), where 1 / u = 2 - u up to (u - 1)^2: c * max(2 - u, 0) replaces
+// the reciprocal.  v_log_f32 is relatively accurate next to 1 (measured over the whole range by
+// tests/test_gpu_parity.py::test_log1p_probe), and for u == 1 the result is c = x exactly.
 __device__ __forceinline__ float log1p_pos(float x) {
     const float u = 1.0f + x;
     const float c = x - (u - 1.0f);
-    return fmaf(c, __builtin_amdgcn_rcpf(u), __builtin_amdgcn_logf(u) * 0.693147180559945309f);
+    return fmaf(c, fmaxf(2.0f - u, 0.0f), __builtin_amdgcn_logf(u) * 0.693147180559945309f);
 }
 
 // W32^j = exp(-2 pi i j / 32), j < 8
@@ -330,6 +343,22 @@ __device__ constexpr double kW32im[8] = {-0.0, -0.19509032201612826785, -0.38268
 // bins 0..1024 except bin 512; lane 0 also owns bin 512 ("mid").
 struct Mags {
     float a[8], b[8], mid;
+    __device__ __forceinline__ float swap_a(int j, float m) { const float t = a[j]; a[j] = m; return t; }
+    __device__ __forceinline__ float swap_b(int j, float m) { const float t = b[j]; b[j] = m; return t; }
+    __device__ __forceinline__ float swap_mid(float m) { const float t = mid; mid = m; return t; }
+};
+
+// The same state parked in LDS (float [17][64] per wave, lane-private columns: no conflicts, no synchronisation):
+// 17 registers fewer across the whole frame for 34 ds_read_b32 / ds_write_b32 per frame.
+struct MagsLds {
+    float* col;          // &area[lane]
+    __device__ __forceinline__ float swap_a(int j, float m) { const float t = col[64 * j]; col[64 * j] = m; return t; }
+    __device__ __forceinline__ float swap_b(int j, float m) {
+        const float t = col[64 * (8 + j)];
+        col[64 * (8 + j)] = m;
+        return t;
+    }
+    __device__ __forceinline__ float swap_mid(float m) { const float t = col[64 * 16]; col[64 * 16] = m; return t; }
 };
 
 // Real-FFT unpack -> |X| -> flux partial vs pm (updated in place) -> log1p.
@@ -339,11 +368,14 @@ struct Mags {
 // lane 0 it is the lane's own register 16 - j (bin 0 pairs with itself: X[0], X[1024] = Re Z[0] +- Im Z[0]).
 // Returns this lane's flux partial.  When emit: log1p|X| is stored to `out` (float32[1025], may be null) as soon
 // as it is known, and lg0 / lg1 receive log1p|X| of bins lane and lane + 64 (band maxima).
-__device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, bool emit, Mags& pm,
+template <typename PM>
+__device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, bool emit, PM& pm,
                                             float* __restrict__ out, float& lg0, float& lg1) {
     const int src_lane4 = ((64 - lane) & 63) * 4;
     const cd wuh = opaque(T.wuh);
     float fl = 0.0f;
+    float* const out_a = out + lane;              // two per-frame addresses; the 64 j steps are instruction offsets
+    float* const out_b = out + (1024 - lane);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         double c = bperm_f64(src_lane4, v[zreg(15 - j)].x);
@@ -364,17 +396,15 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
         const double br = fma(0.5, ex, -tx), bi = fma(0.5, ey, -ty);
         const float ma = mag_from_sq(fma(ar, ar, ai * ai));
         const float mb = mag_from_sq(fma(br, br, bi * bi));
-        fl += fmaxf(0.0f, ma - pm.a[j]);
-        fl += fmaxf(0.0f, mb - pm.b[j]);
-        pm.a[j] = ma;
-        pm.b[j] = mb;
+        fl += fmaxf(0.0f, ma - pm.swap_a(j, ma));
+        fl += fmaxf(0.0f, mb - pm.swap_b(j, mb));
         if (emit) {
             const float la = log1p_pos(ma), lb = log1p_pos(mb);
             if (j == 0) lg0 = la;
             if (j == 1) lg1 = la;
             if (out != nullptr) {
-                out[lane + 64 * j] = la;
-                out[1024 - lane - 64 * j] = lb;
+                out_a[64 * j] = la;               // bin lane + 64 j
+                out_b[-64 * j] = lb;              // bin 1024 - lane - 64 j
             }
         }
     }
@@ -382,8 +412,7 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
         const cd z8 = v[zreg(8)];
         const float mm = mag_from_sq(fma(z8.x, z8.x, z8.y * z8.y));
         if (lane == 0) {
-            fl += fmaxf(0.0f, mm - pm.mid);
-            pm.mid = mm;
+            fl += fmaxf(0.0f, mm - pm.swap_mid(mm));
         }
         if (emit && out != nullptr && lane == 0) out[512] = log1p_pos(mm);
     }
@@ -422,7 +451,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     float* __restrict__ samples_out, float* __restrict__ bandmax) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // readfirstlane: tells the compiler the wave index is wave-uniform, so the frame range, every per-frame pointer
+    // and pos[f] live in scalar registers and the per-frame branches are scalar branches
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const Tables T = stage_tables(window, twid, smem, lane);
 
     double* xb = reinterpret_cast<double*>(smem + kLdsWinBytes + kLdsTw2Bytes) + wave * kXbufDoubles;   // wave-private
@@ -434,7 +465,6 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     if (c0 >= frame_end) return;   // no block-level barrier below this point
     const long cend = (c0 + frames_per_wave < frame_end) ? c0 + frames_per_wave : frame_end;
 
-    float prv[16], cur[16];
     Mags pmag;                            // Analyzer.prev_mag of this wave's bins
     cd v[16];
     mags_zero(pmag);
@@ -443,10 +473,15 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     // Analyzer.buffer starts at zero (analysis.py:14); a chunk that starts inside the track first replays frame
     // c0 - 1 (the halo) to rebuild Analyzer.prev_mag, storing nothing.
     const long fstart = (c0 > 0) ? c0 - 1 : c0;
+    float prv[16], cur[16];
     load_block<C>(audio, n_samp, pos, fstart - 1, hop, lane, prv);
+    load_block<C>(audio, n_samp, pos, fstart, hop, lane, cur);
 
     for (long f = fstart; f < cend; ++f) {
-        load_block<C>(audio, n_samp, pos, f, hop, lane, cur);
+        // The next frame's block is requested (below, after the FFT) before anything of this frame is stored and is
+        // first touched at the end of the loop body: gfx950 counts loads and stores in one in-order counter (vmcnt), so a load issued behind the 17
+        // spectrum stores of a frame could only be waited for by draining those stores first -- microseconds per
+        // frame with nothing to do.
         const bool store = f >= c0;            // wave-uniform
         const long fo = f - frame_begin;
 
@@ -462,6 +497,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
         }
 
         fft_packed(prv, cur, lane, T, xb, v);
+        RawBlock<C> nxt;
+        issue_block<C>(audio, n_samp, pos, (f + 1 < cend) ? f + 1 : -1, hop, lane, nxt);
         // analysis-only pre-pass (carried smoothing state) and the halo frame: no log1p, no spectrum store
         float lg0 = 0.0f, lg1 = 0.0f;
         float fl = unpack_mag(v, lane, T, want_log && store, pmag,
@@ -483,6 +520,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) prv[i] = cur[i];
+        mix_block<C>(nxt, cur);
     }
 }
 
@@ -553,7 +591,7 @@ extern "C" int aur_stft_frames(aur_ctx* ctx, const float* d_audio, int64_t n_sam
     AUR_REQUIRE(n_frames >= 0, "aur_stft_frames: n_frames %d < 0", n_frames);
     if (n_frames == 0) return AUR_OK;
     AUR_REQUIRE(d_audio && d_pos && d_flux_sum && d_meanabs, "aur_stft_frames: null device pointer");
-    AUR_REQUIRE(n_samples > 0, "aur_stft_frames: n_samples %lld <= 0", (long long)n_samples);
+    AUR_REQUIRE(n_samples >= 2, "aur_stft_frames: n_samples %lld < 2", (long long)n_samples);
     AUR_REQUIRE(channels == 1 || channels == 2, "aur_stft_frames: channels %d unsupported (1 or 2)", channels);
     AUR_REQUIRE(hop >= 1, "aur_stft_frames: hop %d < 1", hop);
     AUR_REQUIRE(frame_begin >= 0, "aur_stft_frames: frame_begin %lld < 0", (long long)frame_begin);

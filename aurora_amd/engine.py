@@ -299,16 +299,27 @@ class HipExportEngine:
             self._work = self.empty((max(need.value, 16),), self.torch.uint8)
         return self._work
 
-    def fill(self, spans, K: int, pen_rgb, W: int, H: int, out=None, work=None):
+    def summarize(self, spans, K: int, W: int, H: int, work=None):
+        """Column summaries of `spans` for the linear fill (aur_span_summary) into the work area; returns it."""
+        count = int(spans.shape[0])
+        if work is None:
+            work = self.raster_work(count, W)
+        if W % 16 == 0:
+            _lib.check(self.lib.aur_span_summary(self.ctx.handle, _ptr(spans), K, count, W, H, _ptr(work),
+                                                 work.numel(), self.stream()), "aur_span_summary")
+        return work
+
+    def fill(self, spans, K: int, pen_rgb, W: int, H: int, out=None, work=None, work_ready=False):
         torch = self.torch
         count = int(spans.shape[0])
         if out is None:
             out = self.empty((count, H, W, 3), torch.uint8)
         if work is None:
             work = self.raster_work(count, W)
+            work_ready = False
         _lib.check(self.lib.aur_raster_spans_ws(self.ctx.handle, _ptr(spans), K, _ptr(pen_rgb), count, W, H,
-                                                _ptr(out), _ptr(work), work.numel(), self.stream()),
-                   "aur_raster_spans_ws")
+                                                _ptr(out), _ptr(work), work.numel(), int(bool(work_ready)),
+                                                self.stream()), "aur_raster_spans_ws")
         return out
 
     def fill_tiles(self, spans, K: int, pen_rgb, W: int, H: int, out=None):

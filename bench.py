@@ -143,13 +143,15 @@ def main():
                 planes = eng.radial_planes(prep, an, sc, W, H, done, n, planes_out=dev_spans[s][:, :n])
             else:
                 spans, _ = eng.spans(kind, an, sc, W, H, done, n, out=dev_spans[s][:n])
-            if ev_fill is not None:
+            if radial is None:
+                work = eng.summarize(spans, K, W, H)           # column summaries: their own small kernel
+            if ev_fill is not None:                            # the events bracket the fill kernel alone
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             if radial is not None:
                 eng.fill_planes(planes, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n])
             else:
-                eng.fill(spans, K, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n])
+                eng.fill(spans, K, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n], work=work, work_ready=True)
             if ev_fill is not None:
                 e1.record()
                 ev_fill.append((e0, e1, n))
@@ -187,7 +189,9 @@ def main():
     roof = kernel_stats(ev_fill, frame_bytes)
     roof_stft = kernel_stats(ev_stft, stft_bytes)
     if roof is not None:
-        roof["kernel"] = "raster_fill_planes_kernel" if radial is not None else f"raster_fill16_kernel<{K}>"
+        lin = W % 16 == 0 and os.environ.get("AUR_FILL_MODE", "0") != "1"
+        roof["kernel"] = ("raster_fill_planes_kernel" if radial is not None else
+                          f"raster_fill_lin_kernel<{K}>" if lin else f"raster_fill16_kernel<{K}>")
     if roof_stft is not None:
         roof_stft["kernel"] = f"stft_frames_kernel<{track.channels}>"
     try:                                               # per-launch HBM bytes from separate --pmc passes, if collected

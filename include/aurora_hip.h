@@ -159,13 +159,18 @@ int aur_raster_spans(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t
 
 /* The same frames through the linear fill (one 4 KB-aligned 4 KB piece of the batch per workgroup, one store per lane:
  * the store shape that reaches the HBM write ceiling of MI355X).  d_work: device work area of
- * aur_raster_work_bytes(n_frames, W) bytes, 16-byte aligned, overwritten by every call (per-frame column summaries the
- * fill looks up instead of re-reading spans).  Falls back to aur_raster_spans when d_work is NULL or the shape does
- * not suit (W not a multiple of 16, fewer than 256 16-byte columns per frame, batch above 2^31 columns).
- * Replaces the same reference code as aur_raster_spans; results are byte-identical to it. */
+ * aur_raster_work_bytes(n_frames, W) bytes, 16-byte aligned: per-frame column summaries the fill looks up instead of
+ * re-reading spans.  aur_span_summary builds them from d_spans; aur_raster_spans_ws does that itself unless
+ * work_ready != 0 (d_work already holds the summaries of exactly these spans).  aur_raster_spans_ws falls back to
+ * aur_raster_spans when d_work is NULL or the shape does not suit (W not a multiple of 16, fewer than 256 16-byte
+ * columns per frame, batch above 2^31 columns).  Replaces the same reference code as aur_raster_spans; results are
+ * byte-identical to it. */
 int aur_raster_work_bytes(int n_frames, int W, size_t* out_bytes);
+int aur_span_summary(aur_ctx* ctx, const uint32_t* d_spans, int K, int n_frames, int W, int H, void* d_work,
+                     size_t work_bytes, void* stream);
 int aur_raster_spans_ws(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb /*[F,4]*/,
-                        int n_frames, int W, int H, uint8_t* d_frames, void* d_work, size_t work_bytes, void* stream);
+                        int n_frames, int W, int H, uint8_t* d_frames, void* d_work, size_t work_bytes, int work_ready,
+                        void* stream);
 
 /* ---- "Spectrum - Radial": radial path, centre-disc envelope, bit planes ------------------------------------ */
 

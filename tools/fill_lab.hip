@@ -184,6 +184,51 @@ __global__ __launch_bounds__(256) void store_first_kernel(uint4* __restrict__ p,
     }
 }
 
+// persistent: `grid` resident workgroups walk the buffer together, piece = b, b + grid, b + 2 grid ... (one compact
+// moving window); optional s_sleep between stores
+template <int SLEEP>
+__global__ __launch_bounds__(256) void persist_kernel(uint4* __restrict__ p, long npieces, uint4 val) {
+    for (long piece = blockIdx.x; piece < npieces; piece += gridDim.x) {
+        p[piece * 256 + threadIdx.x] = val;
+        if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+    }
+}
+// one piece per workgroup with a pure delay in front of the store
+template <int SLEEP>
+__global__ __launch_bounds__(256) void delay_kernel(uint4* __restrict__ p, long npieces, uint4 val) {
+    if (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+    p[(long)blockIdx.x * 256 + threadIdx.x] = val;
+}
+
+// lookup + mask path as lin2d mode 1, but the store is held back until T shader-clock cycles after the wave started:
+// stores leave in dispatch order whatever the look-up latency was
+__global__ __launch_bounds__(256) void equalized_kernel(uint4* __restrict__ p, const uint2* __restrict__ colsum,
+                                                        int nu4, int u4_per_frame, float inv_nu4, int T) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const int f = blockIdx.y;
+    const int u0 = blockIdx.x * 256;
+    int row = (int)((float)u0 * inv_nu4);
+    int col = u0 - row * nu4;
+    if (col < 0) { col += nu4; --row; } else if (col >= nu4) { col -= nu4; ++row; }
+    col += threadIdx.x;
+    while (col >= nu4) { col -= nu4; ++row; }
+    const int u = u0 + threadIdx.x;
+    if (u >= u4_per_frame) return;
+    const uint2 s = colsum[f * nu4 + col];
+    const int ph = col % 3;
+    uint4 o = bg_pattern(ph);
+    if ((uint32_t)row - (s.x & 0xffffu) < (s.x >> 16)) {
+        const uint32_t pen = 0x00c8ff20u, bg = 0x00120d0du;
+        uint32_t P[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) P[c] = (s.y >> c) & 1u ? pen : bg;
+        o = pack6(P, ph);
+    }
+    asm volatile("" ::"v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)T) __builtin_amdgcn_s_sleep(1);
+    p[(long)f * u4_per_frame + u] = o;
+}
+
 template <int K>
 __device__ __forceinline__ void writelane(uint32_t& v, uint32_t t) {
     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(t), "n"(K));
@@ -427,6 +472,21 @@ int main() {
         long diff = 0;
         for (size_t i = 0; i < fb; ++i) diff += h1[i] != h2[i];
         printf("store-first vs lin2d mask: %ld differing bytes\n", diff);
+    }
+    {
+        const long np = bytes / 4096;
+#define PERS(G, S) run("persistent grid=" #G " sleep=" #S, [&](uint4* p) { persist_kernel<S><<<G, 256>>>(p, np, val); })
+        PERS(2048, 0); PERS(1024, 0); PERS(4096, 0); PERS(8192, 0); PERS(2048, 1); PERS(2048, 2); PERS(2048, 4); PERS(1024, 2); PERS(512, 0); PERS(512, 1);
+#define DELAY(S) run("one piece, s_sleep " #S " first", [&](uint4* p) { delay_kernel<S><<<(unsigned)np, 256>>>(p, np, val); })
+        DELAY(0); DELAY(1); DELAY(2); DELAY(4); DELAY(8); DELAY(16);
+    }
+    {
+        const int nu4 = W * 3 / 16, upf = nu4 * H;
+        const dim3 g((upf + 255) / 256, F);
+        for (int T : {0, 300, 600, 1000, 1500, 2000, 3000, 5000}) {
+            snprintf(name, sizeof name, "lookup + store at launch + %d cycles", T);
+            run(name, [&](uint4* p) { equalized_kernel<<<g, 256>>>(p, g_colsum, nu4, upf, 1.0f / nu4, T); });
+        }
     }
     for (int shift : {0, 16, 64, 128}) {
         const long np = bytes / (16L * 256);

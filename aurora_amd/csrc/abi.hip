@@ -38,6 +38,9 @@ static void build_tables(float* window, double* tw) {
         const double au = -two_pi * (double)l / 2048.0;
         tw[AUR_TW_WU + 2 * l] = 0.5 * cos(au);
         tw[AUR_TW_WU + 2 * l + 1] = 0.5 * sin(au);
+        const double as = (l == 0) ? -two_pi * 128.0 / 2048.0 : au;
+        tw[AUR_TW_WS + 2 * l] = 0.5 * cos(as);
+        tw[AUR_TW_WS + 2 * l + 1] = 0.5 * sin(as);
     }
     for (int r = 0; r < 4; ++r)
         for (int q = 0; q < 16; ++q) {

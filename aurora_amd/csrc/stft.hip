@@ -19,7 +19,10 @@
 //    coalesced store order of the spectrum (bins l + 64 j) -- no third transpose;
 //  * the transposes move real and imaginary parts separately (ds_write_b64 / ds_read_b64, rows padded to 66
 //    doubles: conflict-free both ways), so a wave needs 8.25 KB of LDS and 12 waves fit a CU next to the tables;
-//  * the unpack partner Z[1024-k] lives in lane (64 - l) % 64 and is fetched with ds_bpermute (no LDS memory);
+//  * the second transpose hands every lane its radix-4 groups in partner pairs: next to the groups that produce
+//    Z[l + 64 j] (j in {0,1,4,5,8,9,12,13}) a lane reads the groups that produce Z[1024 - l - 64 j], so the real-FFT
+//    unpack finds both operands of a bin pair in its own registers (no cross-lane traffic after pass 3);
+//  * wave reductions (flux, mean|x|, band maxima) are DPP row operations, not LDS round trips;
 //  * lane-dependent twiddles W1024^(l k1) and W2048^(l + 64 j) are powers / constant multiples of one per-lane
 //    base value held in registers; the small W64^(r q) table and the window are staged in LDS once per workgroup;
 //  * a wave walks consecutive frames, so the previous 1024-sample block (Analyzer.buffer[:1024]) and the
@@ -29,6 +32,8 @@
 //
 // Contraction is disabled for the whole library (-ffp-contract=off); fma is used explicitly where wanted.
 #include "common.h"
+
+#include <type_traits>
 
 namespace {
 
@@ -98,23 +103,34 @@ __device__ __forceinline__ void dft16(cd (&v)[16]) {
     for (int c = 0; c < 4; ++c) radix4(v[4 * c + 0], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
 }
 
-__device__ __forceinline__ float wave_sum_xor(float v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
+// DPP move: lanes whose row is masked off receive 0 (the identity of the sums and of the maxima of values >= 0 below)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
 }
 
-__device__ __forceinline__ float wave_max_xor(float v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-    return v;
+// Sum over the 64 lanes in the order of an xor butterfly (pairs, quads, 8, 16, 32, 64: numpy's pairwise tree for
+// the mean|x| partials), as DPP row operations: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror,
+// row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3; lane 63 holds the total.  Wave-uniform result.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp0<0xB1, 0xF>(v);
+    v += dpp0<0x4E, 0xF>(v);
+    v += dpp0<0x141, 0xF>(v);
+    v += dpp0<0x140, 0xF>(v);
+    v += dpp0<0x142, 0xA>(v);
+    v += dpp0<0x143, 0xC>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-__device__ __forceinline__ double bperm_f64(int src_lane4, double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_ds_bpermute(src_lane4, (int)(b & 0xffffffffLL));
-    const int hi = __builtin_amdgcn_ds_bpermute(src_lane4, (int)(b >> 32));
-    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+// Maximum over the 64 lanes of values >= 0.  Wave-uniform result.
+__device__ __forceinline__ float wave_max_pos(float v) {
+    v = fmaxf(v, dpp0<0xB1, 0xF>(v));
+    v = fmaxf(v, dpp0<0x4E, 0xF>(v));
+    v = fmaxf(v, dpp0<0x141, 0xF>(v));
+    v = fmaxf(v, dpp0<0x140, 0xF>(v));
+    v = fmaxf(v, dpp0<0x142, 0xA>(v));
+    v = fmaxf(v, dpp0<0x143, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // 16 / 8 bytes of interleaved samples at their natural alignment (frame positions are arbitrary sample offsets)
@@ -202,6 +218,9 @@ struct Tables {
     const cd* tw2;       // LDS: W64^(r q), [r][q]
     cd w1;               // W1024^lane
     cd wuh;              // 0.5 * W2048^lane
+    cd wus;              // the same, except lane 0: 0.5 * W2048^128 (its pairs (640,384), (896,128); see unpack_mag)
+    int b0, b1;          // exchange-2 positions of the partner groups: Z[b + 256 s], s < 4
+    int off2;            // first bin of the slots (ql = 0, s >= 2): lane, except lane 0: 128
 };
 
 // Stages the window and the W64 table into LDS (whole workgroup), loads the per-lane twiddle bases.  Ends with
@@ -218,6 +237,10 @@ __device__ __forceinline__ Tables stage_tables(const float* __restrict__ window,
     t.tw2 = reinterpret_cast<const cd*>(t2);
     t.w1 = cd{twid[AUR_TW_W1 + 2 * lane], twid[AUR_TW_W1 + 2 * lane + 1]};
     t.wuh = cd{twid[AUR_TW_WU + 2 * lane], twid[AUR_TW_WU + 2 * lane + 1]};
+    t.wus = cd{twid[AUR_TW_WS + 2 * lane], twid[AUR_TW_WS + 2 * lane + 1]};
+    t.b0 = (lane == 0) ? 128 : 256 - lane;
+    t.b1 = 192 - lane;
+    t.off2 = (lane == 0) ? 128 : lane;
     __syncthreads();
     return t;
 }
@@ -235,14 +258,16 @@ __device__ __forceinline__ float block_meanabs(const float (&cur)[16], int lane,
     float r = e[0];
 #pragma unroll
     for (int t = 1; t < 16; ++t) r += e[8 * t];
-    r = wave_sum_xor(r);
+    r = wave_sum(r);
     wave_sync();
     return r * (1.0f / 1024.0f);
 }
 
 // 1024-point complex FFT (float64) of the windowed, packed 2048-sample buffer [prv | cur].
 // In: prv/cur[2jj], [2jj+1] = block samples 2*lane + 128*jj, +1.
-// Out: Z[lane + 64 j] is left in v[4 * (j & 3) + (j >> 2)]  (see zreg()).
+// Out (slot p = 4 ql + s, ql < 2, s < 4):  v[p] = Z[lane + 64 (ql + 4 s)],  v[8 + p] = Z[b_ql + 256 s] with
+// b_0 = 256 - lane, b_1 = 192 - lane, i.e. v[8 + 4 ql + (3 - s)] = Z[1024 - (lane + 64 (ql + 4 s))], the unpack
+// partner of v[p].  Lane 0 (whose bins 64 j pair among themselves) reads b_0 = 128 instead: v[8 + s] = Z[128 + 256 s].
 __device__ __forceinline__ void fft_packed(const float (&prv)[16], const float (&cur)[16], int lane,
                                            const Tables& T, double* xb_, cd (&v)[16]) {
     // volatile: keeps one ds_read_b64 / ds_write_b64 per element.  Merged into ds_read2_b64 / ds_write2_b64 the
@@ -299,21 +324,27 @@ __device__ __forceinline__ void fft_packed(const float (&prv)[16], const float (
     for (int i = 0; i < 16; ++i) xb[lo4 + 16 * ((i >> 2) + 4 * (i & 3)) + 256 * hi2] = v[i].x;
     wave_sync();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i].x = xb[lane + 64 * (i >> 2) + 256 * (i & 3)];   // i = 4 ql + r
+    for (int i = 0; i < 8; ++i) v[i].x = xb[lane + 64 * (i >> 2) + 256 * (i & 3)];   // i = 4 ql + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[8 + i].x = xb[T.b0 + 256 * i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[12 + i].x = xb[T.b1 + 256 * i];
     wave_sync();
 #pragma unroll
     for (int i = 0; i < 16; ++i) xb[lo4 + 16 * ((i >> 2) + 4 * (i & 3)) + 256 * hi2] = v[i].y;
     wave_sync();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i].y = xb[lane + 64 * (i >> 2) + 256 * (i & 3)];
-    wave_sync();
-    // pass 3: radix-4 over r (lane = k1 + 16 qh holds q = qh + 4 ql); v[4 ql + s] = Z[lane + 64 (ql + 4 s)]
+    for (int i = 0; i < 8; ++i) v[i].y = xb[lane + 64 * (i >> 2) + 256 * (i & 3)];
 #pragma unroll
-    for (int ql = 0; ql < 4; ++ql) radix4(v[4 * ql + 0], v[4 * ql + 1], v[4 * ql + 2], v[4 * ql + 3]);
+    for (int i = 0; i < 4; ++i) v[8 + i].y = xb[T.b0 + 256 * i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[12 + i].y = xb[T.b1 + 256 * i];
+    wave_sync();
+    // pass 3: radix-4 over r.  Position k1 + 16 q + 256 r of the exchange holds pass-2 output q of lane k1 + 16 r;
+    // the radix-4 over r of the group at base k1 + 16 q yields Z[base + 256 s], s < 4.
+#pragma unroll
+    for (int g = 0; g < 4; ++g) radix4(v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
-
-// register of v[] that holds Z[lane + 64 j] after fft_packed
-__device__ __forceinline__ constexpr int zreg(int j) { return 4 * (j & 3) + (j >> 2); }
 
 // |X| in float32 from |X|^2 in float64: |X|^2 rounded to float32 (relative 2^-24; never outside the float32 range
 // for audio in [-1, 1]: |X| <= 2048, and leakage bins stop at the ~1e-7 rounding noise of the float32 window
@@ -331,119 +362,133 @@ __device__ __forceinline__ float log1p_pos(float x) {
     return fmaf(c, fmaxf(2.0f - u, 0.0f), __builtin_amdgcn_logf(u) * 0.693147180559945309f);
 }
 
-// W32^j = exp(-2 pi i j / 32), j < 8
-__device__ constexpr double kW32re[8] = {1.0, 0.98078528040323044913, 0.92387953251128675613,
-                                         0.83146961230254523708, 0.70710678118654752440, 0.55557023301960222474,
-                                         0.38268343236508977173, 0.19509032201612826785};
-__device__ constexpr double kW32im[8] = {-0.0, -0.19509032201612826785, -0.38268343236508977173,
-                                         -0.55557023301960222474, -0.70710678118654752440, -0.83146961230254523708,
-                                         -0.92387953251128675613, -0.98078528040323044913};
+// W32^j = exp(-2 pi i j / 32) for j = 1, 5
+constexpr double kW32re1 = 0.98078528040323044913, kW32im1 = -0.19509032201612826785;
+constexpr double kW32re5 = 0.55557023301960222474, kW32im5 = -0.83146961230254523708;
 
-// Per-lane spectrum state: lane l owns the bin pairs (kA, kB) = (l + 64 j, 1024 - l - 64 j), j < 8, which tile
-// bins 0..1024 except bin 512; lane 0 also owns bin 512 ("mid").
+// Per-lane spectrum state.  Slot p = 4 ql + s (ql < 2, s < 4) of lane l is the bin pair (kA, 1024 - kA) with
+// kA = l + 64 (ql + 4 s); in lane 0 the slots (ql = 0, s >= 2) are kA = 640, 896 instead (see unpack_mag).  The 512
+// pairs tile bins 0..1024 except bin 512, which lane 0 owns as "mid".
+__device__ __forceinline__ int slot_bin(int lane, int p) {
+    const int ql = p >> 2, s = p & 3;
+    return lane + 64 * (ql + 4 * s) + ((lane == 0 && ql == 0 && s >= 2) ? 128 : 0);
+}
+
 struct Mags {
     float a[8], b[8], mid;
-    __device__ __forceinline__ float swap_a(int j, float m) { const float t = a[j]; a[j] = m; return t; }
-    __device__ __forceinline__ float swap_b(int j, float m) { const float t = b[j]; b[j] = m; return t; }
+    __device__ __forceinline__ float swap_a(int p, float m) { const float t = a[p]; a[p] = m; return t; }
+    __device__ __forceinline__ float swap_b(int p, float m) { const float t = b[p]; b[p] = m; return t; }
     __device__ __forceinline__ float swap_mid(float m) { const float t = mid; mid = m; return t; }
 };
 
-// The same state parked in LDS (float [17][64] per wave, lane-private columns: no conflicts, no synchronisation):
-// 17 registers fewer across the whole frame for 34 ds_read_b32 / ds_write_b32 per frame.
-struct MagsLds {
-    float* col;          // &area[lane]
-    __device__ __forceinline__ float swap_a(int j, float m) { const float t = col[64 * j]; col[64 * j] = m; return t; }
-    __device__ __forceinline__ float swap_b(int j, float m) {
-        const float t = col[64 * (8 + j)];
-        col[64 * (8 + j)] = m;
-        return t;
-    }
-    __device__ __forceinline__ float swap_mid(float m) { const float t = col[64 * 16]; col[64 * 16] = m; return t; }
-};
-
 // Real-FFT unpack -> |X| -> flux partial vs pm (updated in place) -> log1p.
-// X[kA] = E + T and X[kB] = conj(E - T) share E = (Z[kA] + conj Z[1024 - kA]) / 2 and
-// T = W2048^kA * (-i) (Z[kA] - conj Z[1024 - kA]) / 2, so a lane computes both bins of a pair from one product.
-// The partner Z[1024 - kA] sits in lane (64 - l) % 64, register j' = 15 - j, and is fetched with ds_bpermute; in
-// lane 0 it is the lane's own register 16 - j (bin 0 pairs with itself: X[0], X[1024] = Re Z[0] +- Im Z[0]).
-// Returns this lane's flux partial.  When emit: log1p|X| is stored to `out` (float32[1025], may be null) as soon
-// as it is known, and lg0 / lg1 receive log1p|X| of bins lane and lane + 64 (band maxima).
-template <typename PM>
-__device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, bool emit, PM& pm,
+// X[kA] = E + T and X[kB] = conj(E - T), kB = 1024 - kA, share E = (Z[kA] + conj Z[kB]) / 2 and
+// T = W2048^kA * (-i) (Z[kA] - conj Z[kB]) / 2, so a lane computes both bins of a pair from one product.
+// fft_packed leaves both operands of a pair in the lane: slot p = 4 ql + s pairs v[p] = Z[kA] with
+// v[8 + 4 ql + (3 - s)] = Z[kB].  Lane 0 is the exception for ql = 0: its bins 0, 128, .., 1024 pair among themselves.
+// It holds Z[256 s] in v[s] and Z[128 + 256 s] in v[8 + s] and wires its four slots as
+//   s = 0: (Z[0], Z[0]) -> X[0], X[1024]      s = 2: (Z[640], Z[384])   (generic kA shifted by 128)
+//   s = 1: (Z[256], Z[768])                   s = 3: (Z[896], Z[128])   (generic kA shifted by 128)
+// which costs 16 selects; X[512] = conj Z[512] = conj v[2] is the extra "mid" bin.
+// Twiddles th = 0.5 W2048^kA = wuh W32^j, j = ql + 4 s: W32^4 = (1 - i) / sqrt 2, W32^8 = -i, so only W32^1 and
+// W32^5 need a full product; T.wus equals T.wuh except in lane 0, where it carries the shift by 128 bins.
+// Returns this lane's flux partial.  When EMIT: lg0 / lg1 receive log1p|X| of bins lane and lane + 64 (band maxima),
+// and when STORE_LOG too, log1p|X| is stored to `out` (float32[1025]) as soon as it is known.
+template <bool EMIT, bool STORE_LOG, typename PM>
+__device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, PM& pm,
                                             float* __restrict__ out, float& lg0, float& lg1) {
-    const int src_lane4 = ((64 - lane) & 63) * 4;
+    constexpr double H = 0.70710678118654752440;
+    const bool l0 = lane == 0;
     const cd wuh = opaque(T.wuh);
+    const cd wus = opaque(T.wus);
+    cd th[8];
+    th[0] = wuh;                                                       // j = 0
+    th[1] = cd{H * (wuh.x + wuh.y), H * (wuh.y - wuh.x)};              // j = 4
+    th[2] = mul_mi(wus);                                               // j = 8
+    th[3] = mul_mi(cd{H * (wus.x + wus.y), H * (wus.y - wus.x)});      // j = 12
+    th[4] = cmul(wuh, cd{kW32re1, kW32im1});                           // j = 1
+    th[5] = cmul(wuh, cd{kW32re5, kW32im5});                           // j = 5
+    th[6] = mul_mi(th[4]);                                             // j = 9
+    th[7] = mul_mi(th[5]);                                             // j = 13
     float fl = 0.0f;
-    float* const out_a = out + lane;              // two per-frame addresses; the 64 j steps are instruction offsets
+    // per-frame store addresses; the 64 j steps are instruction offsets
+    float* const out_a = out + lane;
     float* const out_b = out + (1024 - lane);
+    float* const out_a2 = out + T.off2;
+    float* const out_b2 = out + (1024 - T.off2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        double c = bperm_f64(src_lane4, v[zreg(15 - j)].x);
-        double d = bperm_f64(src_lane4, v[zreg(15 - j)].y);
-        if (lane == 0) {
-            const cd own = (j == 0) ? v[zreg(0)] : v[zreg(16 - j)];
-            c = own.x;
-            d = own.y;
-        }
-        const double a = v[zreg(j)].x, b = v[zreg(j)].y;
-        // th = 0.5 * W2048^(lane + 64 j) = wuh * W32^j
-        const cd th = (j == 0) ? wuh : cmul(wuh, cd{kW32re[j], kW32im[j]});
+    for (int p = 0; p < 8; ++p) {
+        const int ql = p >> 2, s = p & 3, j = ql + 4 * s;
+        cd A = v[p], P = v[8 + 4 * ql + (3 - s)];
+        if (p == 0) P = cd{l0 ? v[0].x : P.x, l0 ? v[0].y : P.y};
+        if (p == 1) P = cd{l0 ? v[3].x : P.x, l0 ? v[3].y : P.y};
+        if (p == 2) A = cd{l0 ? v[10].x : A.x, l0 ? v[10].y : A.y};
+        if (p == 3) A = cd{l0 ? v[11].x : A.x, l0 ? v[11].y : A.y};
+        const double a = A.x, b = A.y, c = P.x, d = P.y;
         const double ex = a + c, ey = b - d;     // 2E
-        const double ox = b + d, oy = c - a;     // 2O = -i (Z[k] - conj(Z[N-k]))
-        const double tx = fma(th.x, ox, -(th.y * oy));
-        const double ty = fma(th.x, oy, th.y * ox);
+        const double ox = b + d, oy = c - a;     // 2O = -i (Z[kA] - conj Z[kB])
+        const double tx = fma(th[p].x, ox, -(th[p].y * oy));
+        const double ty = fma(th[p].x, oy, th[p].y * ox);
         const double ar = fma(0.5, ex, tx), ai = fma(0.5, ey, ty);
         const double br = fma(0.5, ex, -tx), bi = fma(0.5, ey, -ty);
         const float ma = mag_from_sq(fma(ar, ar, ai * ai));
         const float mb = mag_from_sq(fma(br, br, bi * bi));
-        fl += fmaxf(0.0f, ma - pm.swap_a(j, ma));
-        fl += fmaxf(0.0f, mb - pm.swap_b(j, mb));
-        if (emit) {
+        fl += fmaxf(0.0f, ma - pm.swap_a(p, ma));
+        fl += fmaxf(0.0f, mb - pm.swap_b(p, mb));
+        if (EMIT) {
             const float la = log1p_pos(ma), lb = log1p_pos(mb);
             if (j == 0) lg0 = la;
             if (j == 1) lg1 = la;
-            if (out != nullptr) {
-                out_a[64 * j] = la;               // bin lane + 64 j
-                out_b[-64 * j] = lb;              // bin 1024 - lane - 64 j
+            if (STORE_LOG) {
+                if (p == 2 || p == 3) {
+                    out_a2[64 * j] = la;          // bin off2 + 64 j
+                    out_b2[-64 * j] = lb;
+                } else {
+                    out_a[64 * j] = la;           // bin lane + 64 j
+                    out_b[-64 * j] = lb;          // bin 1024 - lane - 64 j
+                }
             }
         }
     }
     {   // bin 512 (lane 0): X[512] = conj(Z[512])
-        const cd z8 = v[zreg(8)];
+        const cd z8 = v[2];
         const float mm = mag_from_sq(fma(z8.x, z8.x, z8.y * z8.y));
-        if (lane == 0) {
+        if (l0) {
             fl += fmaxf(0.0f, mm - pm.swap_mid(mm));
+            if (EMIT && STORE_LOG) out[512] = log1p_pos(mm);
         }
-        if (emit && out != nullptr && lane == 0) out[512] = log1p_pos(mm);
     }
     return fl;
 }
 
 __device__ __forceinline__ void mags_zero(Mags& m) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m.a[j] = m.b[j] = 0.0f;
+    for (int p = 0; p < 8; ++p) m.a[p] = m.b[p] = 0.0f;
     m.mid = 0.0f;
 }
 
 __device__ __forceinline__ void mags_load(Mags& m, const float* __restrict__ src, int lane) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        m.a[j] = src[lane + 64 * j];
-        m.b[j] = src[1024 - lane - 64 * j];
+    for (int p = 0; p < 8; ++p) {
+        const int k = slot_bin(lane, p);
+        m.a[p] = src[k];
+        m.b[p] = src[1024 - k];
     }
     m.mid = src[512];
 }
 
 __device__ __forceinline__ void mags_store(const Mags& m, float* __restrict__ dst, int lane) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        dst[lane + 64 * j] = m.a[j];
-        dst[1024 - lane - 64 * j] = m.b[j];
+    for (int p = 0; p < 8; ++p) {
+        const int k = slot_bin(lane, p);
+        dst[k] = m.a[p];
+        dst[1024 - k] = m.b[p];
     }
     if (lane == 0) dst[512] = m.mid;
 }
 
-template <int C>
+// LOG: logspec is stored; BM: band maxima are stored; SAMPLES: the mono blocks are stored (waveform mode).
+template <int C, bool LOG, bool BM, bool SAMPLES>
 __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stft_frames_kernel(
     const float* __restrict__ audio, long n_samp, const long* __restrict__ pos, long frame_begin, int n_frames,
     int hop, int frames_per_wave, const float* __restrict__ window, const double* __restrict__ twid,
@@ -468,7 +513,6 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     Mags pmag;                            // Analyzer.prev_mag of this wave's bins
     cd v[16];
     mags_zero(pmag);
-    const bool want_log = (logspec != nullptr) || (bandmax != nullptr);
 
     // Analyzer.buffer starts at zero (analysis.py:14); a chunk that starts inside the track first replays frame
     // c0 - 1 (the halo) to rebuild Analyzer.prev_mag, storing nothing.
@@ -477,41 +521,35 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     load_block<C>(audio, n_samp, pos, fstart - 1, hop, lane, prv);
     load_block<C>(audio, n_samp, pos, fstart, hop, lane, cur);
 
-    for (long f = fstart; f < cend; ++f) {
-        // The next frame's block is requested (below, after the FFT) before anything of this frame is stored and is
-        // first touched at the end of the loop body: gfx950 counts loads and stores in one in-order counter (vmcnt), so a load issued behind the 17
-        // spectrum stores of a frame could only be waited for by draining those stores first -- microseconds per
-        // frame with nothing to do.
-        const bool store = f >= c0;            // wave-uniform
+    // One frame.  STORE = false is the halo frame: transform and magnitudes only.  The next frame's block is
+    // requested after the FFT, before anything of this frame is stored, and is first touched at the end of the body:
+    // gfx950 counts loads and stores in one in-order counter (vmcnt), so a load issued behind the 17 spectrum stores
+    // of a frame could only be waited for by draining those stores first.
+    auto frame = [&](long f, auto store_tag) {
+        constexpr bool STORE = decltype(store_tag)::value;
         const long fo = f - frame_begin;
-
-        if (store) {
+        if (STORE) {
             const float ma = block_meanabs(cur, lane, xf);
             if (lane == 0) meanabs[fo] = ma;
-            if (samples_out != nullptr) {
+            if (SAMPLES) {
                 float* dst = samples_out + fo * AUR_BLOCK;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj)
                     *reinterpret_cast<float2*>(dst + 2 * lane + 128 * jj) = float2{cur[2 * jj], cur[2 * jj + 1]};
             }
         }
-
         fft_packed(prv, cur, lane, T, xb, v);
         RawBlock<C> nxt;
         issue_block<C>(audio, n_samp, pos, (f + 1 < cend) ? f + 1 : -1, hop, lane, nxt);
-        // analysis-only pre-pass (carried smoothing state) and the halo frame: no log1p, no spectrum store
         float lg0 = 0.0f, lg1 = 0.0f;
-        float fl = unpack_mag(v, lane, T, want_log && store, pmag,
-                              (logspec != nullptr) ? logspec + fo * AUR_NBINS : nullptr, lg0, lg1);
-        if (store) {
-            fl = wave_sum_xor(fl);
+        float fl = unpack_mag<STORE && (LOG || BM), STORE && LOG>(v, lane, T, pmag, logspec + fo * AUR_NBINS, lg0, lg1);
+        if (STORE) {
+            fl = wave_sum(fl);
             if (lane == 0) flux_sum[fo] = fl;
-            if (bandmax != nullptr) {
+            if (BM) {
                 // bins < 80: j = 0 (all lanes) and j = 1 (lanes < 16); bins < 50: j = 0, lanes < 50.  log1p >= 0.
-                float bm80 = fmaxf(lg0, (lane < 16) ? lg1 : 0.0f);
-                float bm50 = (lane < 50) ? lg0 : 0.0f;
-                bm80 = wave_max_xor(bm80);
-                bm50 = wave_max_xor(bm50);
+                const float bm80 = wave_max_pos(fmaxf(lg0, (lane < 16) ? lg1 : 0.0f));
+                const float bm50 = wave_max_pos((lane < 50) ? lg0 : 0.0f);
                 if (lane == 0) {
                     bandmax[2 * fo] = bm80;
                     bandmax[2 * fo + 1] = bm50;
@@ -521,7 +559,14 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
 #pragma unroll
         for (int i = 0; i < 16; ++i) prv[i] = cur[i];
         mix_block<C>(nxt, cur);
+    };
+
+    long f = fstart;
+    if (c0 > 0) {
+        frame(f, std::false_type{});
+        ++f;
     }
+    for (; f < cend; ++f) frame(f, std::true_type{});
 }
 
 // One Analyzer.compute step (audio/analysis.py:25-33) on an already-slid 2048-sample buffer: one wave.
@@ -550,9 +595,9 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
     mags_load(pmag, prev_mag, lane);
     fft_packed(prv, cur, lane, T, xb, v);
     float lg0, lg1;
-    float fl = unpack_mag(v, lane, T, true, pmag, logspec, lg0, lg1);
+    float fl = unpack_mag<true, true>(v, lane, T, pmag, logspec, lg0, lg1);
     mags_store(pmag, prev_mag, lane);
-    fl = wave_sum_xor(fl);
+    fl = wave_sum(fl);
     if (lane == 0) flux_sum[0] = fl;
 }
 
@@ -562,7 +607,7 @@ __global__ __launch_bounds__(256) void log1p_probe_kernel(const float* __restric
     if (i < n) y[i] = log1p_pos(x[i]);
 }
 
-template <int C>
+template <int C, bool LOG, bool BM, bool SAMPLES>
 int launch_stft(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int64_t* d_pos, int64_t frame_begin,
                 int n_frames, int hop, float* d_logspec, float* d_flux_sum, float* d_meanabs, float* d_samples,
                 float* d_bandmax, hipStream_t st) {
@@ -573,11 +618,29 @@ int launch_stft(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int
     if (ctx->stft_fpw > 0) fpw = ctx->stft_fpw;
     const long n_waves = ((long)n_frames + fpw - 1) / fpw;
     const unsigned grid = (unsigned)((n_waves + kWavesPerWG - 1) / kWavesPerWG);
-    hipLaunchKernelGGL(stft_frames_kernel<C>, dim3(grid), dim3(kWavesPerWG * 64), kLdsBytes, st, d_audio,
-                       (long)n_samples, (const long*)d_pos, (long)frame_begin, n_frames, hop, fpw, ctx->d_window,
-                       ctx->d_twid, d_logspec, d_flux_sum, d_meanabs, d_samples, d_bandmax);
+    hipLaunchKernelGGL((stft_frames_kernel<C, LOG, BM, SAMPLES>), dim3(grid), dim3(kWavesPerWG * 64), kLdsBytes, st,
+                       d_audio, (long)n_samples, (const long*)d_pos, (long)frame_begin, n_frames, hop, fpw,
+                       ctx->d_window, ctx->d_twid, d_logspec, d_flux_sum, d_meanabs, d_samples, d_bandmax);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
+}
+
+// Which outputs are wanted is a compile-time property of the kernel (no branches in the frame loop).
+template <int C, bool LOG, bool BM>
+int launch_stft_s(bool samples, aur_ctx* ctx, const float* a, int64_t n, const int64_t* p, int64_t fb, int nf, int hop,
+                  float* ls, float* fs, float* ma, float* sm, float* bm, hipStream_t st) {
+    return samples ? launch_stft<C, LOG, BM, true>(ctx, a, n, p, fb, nf, hop, ls, fs, ma, sm, bm, st)
+                   : launch_stft<C, LOG, BM, false>(ctx, a, n, p, fb, nf, hop, ls, fs, ma, sm, bm, st);
+}
+template <int C>
+int launch_stft_c(aur_ctx* ctx, const float* a, int64_t n, const int64_t* p, int64_t fb, int nf, int hop, float* ls,
+                  float* fs, float* ma, float* sm, float* bm, hipStream_t st) {
+    const bool s = sm != nullptr;
+    if (ls != nullptr)
+        return bm != nullptr ? launch_stft_s<C, true, true>(s, ctx, a, n, p, fb, nf, hop, ls, fs, ma, sm, bm, st)
+                             : launch_stft_s<C, true, false>(s, ctx, a, n, p, fb, nf, hop, ls, fs, ma, sm, bm, st);
+    return bm != nullptr ? launch_stft_s<C, false, true>(s, ctx, a, n, p, fb, nf, hop, ls, fs, ma, sm, bm, st)
+                         : launch_stft_s<C, false, false>(s, ctx, a, n, p, fb, nf, hop, ls, fs, ma, sm, bm, st);
 }
 
 }  // namespace
@@ -601,10 +664,10 @@ extern "C" int aur_stft_frames(aur_ctx* ctx, const float* d_audio, int64_t n_sam
     static_assert(kLdsBytes <= 48 * 1024, "dynamic LDS above 48 KB needs hipFuncSetAttribute");
     hipStream_t st = (hipStream_t)stream;
     if (channels == 2)
-        return launch_stft<2>(ctx, d_audio, n_samples, d_pos, frame_begin, n_frames, hop, d_logspec, d_flux_sum,
-                              d_meanabs, d_samples, d_bandmax, st);
-    return launch_stft<1>(ctx, d_audio, n_samples, d_pos, frame_begin, n_frames, hop, d_logspec, d_flux_sum,
-                          d_meanabs, d_samples, d_bandmax, st);
+        return launch_stft_c<2>(ctx, d_audio, n_samples, d_pos, frame_begin, n_frames, hop, d_logspec, d_flux_sum,
+                                d_meanabs, d_samples, d_bandmax, st);
+    return launch_stft_c<1>(ctx, d_audio, n_samples, d_pos, frame_begin, n_frames, hop, d_logspec, d_flux_sum,
+                            d_meanabs, d_samples, d_bandmax, st);
 }
 
 extern "C" int aur_stft_buffer(aur_ctx* ctx, const float* d_buffer, float* d_prev_mag, float* d_logspec,

@@ -42,6 +42,12 @@ static void build_tables(float* window, double* tw) {
         tw[AUR_TW_WS + 2 * l] = 0.5 * cos(as);
         tw[AUR_TW_WS + 2 * l + 1] = 0.5 * sin(as);
     }
+    for (int k = 1; k < 16; ++k)
+        for (int l = 0; l < 64; ++l) {
+            const double a = -two_pi * (double)((l * k) % 1024) / 1024.0;
+            tw[AUR_TW_P1 + 2 * ((k - 1) * 64 + l)] = cos(a);
+            tw[AUR_TW_P1 + 2 * ((k - 1) * 64 + l) + 1] = sin(a);
+        }
     for (int r = 0; r < 4; ++r)
         for (int q = 0; q < 16; ++q) {
             const double a = -two_pi * (double)(r * q) / 64.0;

@@ -45,7 +45,9 @@ constexpr int kXbufDoubles = 16 * 66;            // exchange buffer per wave: 16
 constexpr int kLdsWinBytes = AUR_FFT_SIZE * 4;   // float32 window
 constexpr int kTw2Stride = 17;                   // complex doubles per W64 row (16 + 1 pad: rows on distinct banks)
 constexpr int kLdsTw2Bytes = 4 * kTw2Stride * 16;   // W64^(r q), complex double
-constexpr int kLdsBytes = kLdsWinBytes + kLdsTw2Bytes + kWavesPerWG * kXbufDoubles * 8;
+constexpr int kLdsTw1Bytes = 15 * 64 * 16;          // W1024^(l k1), complex double [k1 - 1][l]
+constexpr int kLdsTabBytes = kLdsWinBytes + kLdsTw2Bytes + kLdsTw1Bytes;
+constexpr int kLdsBytes = kLdsTabBytes + kWavesPerWG * kXbufDoubles * 8;
 
 struct cd {
     double x, y;
@@ -216,7 +218,7 @@ __device__ __forceinline__ void load_block(const float* __restrict__ audio, long
 struct Tables {
     const float2* win;   // LDS: (w[2n], w[2n+1]), n < 1024
     const cd* tw2;       // LDS: W64^(r q), [r][q]
-    cd w1;               // W1024^lane
+    const cd* tw1;       // LDS: &W1024^(lane k1)[k1 - 1][lane]; rows are 64 complex doubles (ds_read_b128, lane-linear)
     cd wuh;              // 0.5 * W2048^lane
     cd wus;              // the same, except lane 0: 0.5 * W2048^128 (its pairs (640,384), (896,128); see unpack_mag)
     int b0, b1;          // exchange-2 positions of the partner groups: Z[b + 256 s], s < 4
@@ -235,7 +237,10 @@ __device__ __forceinline__ Tables stage_tables(const float* __restrict__ window,
     Tables t;
     t.win = reinterpret_cast<const float2*>(smem);
     t.tw2 = reinterpret_cast<const cd*>(t2);
-    t.w1 = cd{twid[AUR_TW_W1 + 2 * lane], twid[AUR_TW_W1 + 2 * lane + 1]};
+    double2* t1 = reinterpret_cast<double2*>(smem + kLdsWinBytes + kLdsTw2Bytes);
+    const double2* t1src = reinterpret_cast<const double2*>(twid + AUR_TW_P1);
+    for (int i = threadIdx.x; i < 15 * 64; i += blockDim.x) t1[i] = t1src[i];
+    t.tw1 = reinterpret_cast<const cd*>(t1) + lane;
     t.wuh = cd{twid[AUR_TW_WU + 2 * lane], twid[AUR_TW_WU + 2 * lane + 1]};
     t.wus = cd{twid[AUR_TW_WS + 2 * lane], twid[AUR_TW_WS + 2 * lane + 1]};
     t.b0 = (lane == 0) ? 128 : 256 - lane;
@@ -288,17 +293,12 @@ __device__ __forceinline__ void fft_packed(const float (&prv)[16], const float (
     }
     // pass 1: radix-16 over j, twiddle W1024^(l k1), transpose through LDS (rows padded to 66: conflict-free)
     dft16(v);
-    {
-        // W1024^(l k1) as a running product of the per-lane base: two live complex values, rebuilt per frame
-        // (a 15-entry power table kept across frames would pin 60 VGPRs)
-        const cd w1 = opaque(T.w1);
-        cd p = w1;
+    // twiddle W1024^(l k1) from the LDS table (one ds_read_b128 per value: the LDS array has cycles to spare, the
+    // float64 VALU does not -- building the powers per frame cost 56 of its instructions)
 #pragma unroll
-        for (int k1 = 1; k1 < 16; ++k1) {
-            const int i = 4 * (k1 & 3) + (k1 >> 2);     // register that holds output k1 of dft16
-            v[i] = cmul(v[i], p);
-            if (k1 < 15) p = cmul(p, w1);
-        }
+    for (int k1 = 1; k1 < 16; ++k1) {
+        const int i = 4 * (k1 & 3) + (k1 >> 2);     // register that holds output k1 of dft16
+        v[i] = cmul(v[i], T.tw1[64 * (k1 - 1)]);
     }
     const int lo4 = lane & 15, hi2 = lane >> 4;
 #pragma unroll
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const Tables T = stage_tables(window, twid, smem, lane);
 
-    double* xb = reinterpret_cast<double*>(smem + kLdsWinBytes + kLdsTw2Bytes) + wave * kXbufDoubles;   // wave-private
+    double* xb = reinterpret_cast<double*>(smem + kLdsTabBytes) + wave * kXbufDoubles;   // wave-private
     float* xf = reinterpret_cast<float*>(xb);
 
     const long gw = (long)blockIdx.x * kWavesPerWG + wave;
@@ -576,10 +576,10 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
                                                          const double* __restrict__ twid,
                                                          float* __restrict__ logspec,
                                                          float* __restrict__ flux_sum) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsWinBytes + kLdsTw2Bytes + kXbufDoubles * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsTabBytes + kXbufDoubles * 8];
     const int lane = threadIdx.x;
     const Tables T = stage_tables(window, twid, smem, lane);
-    double* xb = reinterpret_cast<double*>(smem + kLdsWinBytes + kLdsTw2Bytes);
+    double* xb = reinterpret_cast<double*>(smem + kLdsTabBytes);
     float prv[16], cur[16];
     Mags pmag;
     cd v[16];
@@ -661,7 +661,7 @@ extern "C" int aur_stft_frames(aur_ctx* ctx, const float* d_audio, int64_t n_sam
     AUR_REQUIRE(((uintptr_t)d_audio & 7u) == 0 &&
                     (d_samples == nullptr || ((uintptr_t)d_samples & 7u) == 0),
                 "aur_stft_frames: misaligned device pointer");
-    static_assert(kLdsBytes <= 48 * 1024, "dynamic LDS above 48 KB needs hipFuncSetAttribute");
+    static_assert(kLdsBytes <= 64 * 1024, "dynamic LDS above 64 KB needs hipFuncSetAttribute");
     hipStream_t st = (hipStream_t)stream;
     if (channels == 2)
         return launch_stft_c<2>(ctx, d_audio, n_samples, d_pos, frame_begin, n_frames, hop, d_logspec, d_flux_sum,

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Lesion builds of the STFT kernel (timing experiments only; the results of these variants are WRONG by design):
+# each variant removes one part of the frame body so its share of the launch time can be read off
+# tools/stft_bench.py.  Build here (CPU):  bash tools/stft_lesion.sh build
+# Run on the GPU box:                     bash tools/stft_lesion.sh run
+set -e
+cd "$(dirname "$0")/.."
+SRC=aurora_amd/csrc
+OUT=build_lesion
+variants="${VARIANTS:-base noexch nostore nomean noload compute}"
+if [ "$1" = build ]; then
+  rm -rf $OUT && mkdir -p $OUT
+  for v in $variants; do
+    d=$OUT/$v; mkdir -p $d/aurora_amd/csrc $d/include
+    cp $SRC/*.hip $SRC/common.h $SRC/Makefile $d/aurora_amd/csrc/; cp include/aurora_hip.h $d/include/
+    f=$d/aurora_amd/csrc/stft.hip
+    case $v in
+      noexch)  python3 -c "import re,sys; s=open(sys.argv[1]).read(); s=re.sub(r'#pragma unroll\n    for \([^\n]*\) [^\n]*xb\[[^\n]*\n','',s); open(sys.argv[1],'w').write(s)" $f ;;
+      nostore) sed -i '/out_a2\?\[.*\] = la;/d; /out_b2\?\[.*\] = lb;/d' $f ;;
+      nomean)  sed -i 's/const float ma = block_meanabs(cur, lane, xf);/const float ma = cur[0];/' $f ;;
+      compute) python3 -c "import re,sys; s=open(sys.argv[1]).read(); s=re.sub(r'#pragma unroll\n    for \([^\n]*\) [^\n]*xb\[[^\n]*\n','',s); open(sys.argv[1],'w').write(s)" $f
+               sed -i '/out_a2\?\[.*\] = la;/d; /out_b2\?\[.*\] = lb;/d' $f
+               sed -i 's/(f + 1 < cend) ? f + 1 : -1, hop, lane, nxt);/fstart, hop, lane, nxt);/' $f ;;
+      noload)  sed -i 's/(f + 1 < cend) ? f + 1 : -1, hop, lane, nxt);/fstart, hop, lane, nxt);/' $f ;;
+    esac
+    make -s -C $d/aurora_amd/csrc OUT=../../lib_$v.so BUILD=build > /dev/null
+    mv $d/lib_$v.so $OUT/ 2>/dev/null || mv $d/aurora_amd/lib_$v.so $OUT/ 2>/dev/null || true
+    rm -rf $d
+  done
+  ls -la $OUT
+else
+  for v in $variants; do
+    echo "== $v"
+    AURORA_HIP_LIB=$PWD/$OUT/lib_$v.so timeout -k 10 100 python tools/stft_bench.py --reps 10 2>&1 | grep stft:
+  done
+fi

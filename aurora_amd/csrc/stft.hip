@@ -40,7 +40,13 @@ namespace {
 #ifndef AUR_STFT_WAVES_PER_SIMD
 #define AUR_STFT_WAVES_PER_SIMD 2      // register budget of the frame kernel: 512 / this VGPRs per lane
 #endif
-constexpr int kWavesPerWG = 4;
+#ifndef AUR_STFT_WAVES_PER_WG
+#define AUR_STFT_WAVES_PER_WG 4
+#endif
+#ifndef AUR_STFT_MID_AT
+#define AUR_STFT_MID_AT 0              // unpack slot before which the next block's loads are issued (0: before the unpack)
+#endif
+constexpr int kWavesPerWG = AUR_STFT_WAVES_PER_WG;
 constexpr int kXbufDoubles = 16 * 66;            // exchange buffer per wave: 16 rows of 66 doubles, 8448 B
 constexpr int kLdsWinBytes = AUR_FFT_SIZE * 4;   // float32 window
 constexpr int kTw2Stride = 17;                   // complex doubles per W64 row (16 + 1 pad: rows on distinct banks)
@@ -394,9 +400,9 @@ struct Mags {
 // W32^5 need a full product; T.wus equals T.wuh except in lane 0, where it carries the shift by 128 bins.
 // Returns this lane's flux partial.  When EMIT: lg0 / lg1 receive log1p|X| of bins lane and lane + 64 (band maxima),
 // and when STORE_LOG too, log1p|X| is stored to `out` (float32[1025]) as soon as it is known.
-template <bool EMIT, bool STORE_LOG, typename PM>
+template <bool EMIT, bool STORE_LOG, typename PM, typename MID>
 __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, PM& pm,
-                                            float* __restrict__ out, float& lg0, float& lg1) {
+                                            float* __restrict__ out, float& lg0, float& lg1, MID&& mid_hook) {
     constexpr double H = 0.70710678118654752440;
     const bool l0 = lane == 0;
     const cd wuh = opaque(T.wuh);
@@ -419,6 +425,7 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int ql = p >> 2, s = p & 3, j = ql + 4 * s;
+        if (p == AUR_STFT_MID_AT) mid_hook();   // half of v[] is dead from here on
         cd A = v[p], P = v[8 + 4 * ql + (3 - s)];
         if (p == 0) P = cd{l0 ? v[0].x : P.x, l0 ? v[0].y : P.y};
         if (p == 1) P = cd{l0 ? v[3].x : P.x, l0 ? v[3].y : P.y};
@@ -540,9 +547,10 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
         }
         fft_packed(prv, cur, lane, T, xb, v);
         RawBlock<C> nxt;
-        issue_block<C>(audio, n_samp, pos, (f + 1 < cend) ? f + 1 : -1, hop, lane, nxt);
         float lg0 = 0.0f, lg1 = 0.0f;
-        float fl = unpack_mag<STORE && (LOG || BM), STORE && LOG>(v, lane, T, pmag, logspec + fo * AUR_NBINS, lg0, lg1);
+        float fl = unpack_mag<STORE && (LOG || BM), STORE && LOG>(
+            v, lane, T, pmag, logspec + fo * AUR_NBINS, lg0, lg1,
+            [&]() { issue_block<C>(audio, n_samp, pos, (f + 1 < cend) ? f + 1 : -1, hop, lane, nxt); });
         if (STORE) {
             fl = wave_sum(fl);
             if (lane == 0) flux_sum[fo] = fl;
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
     mags_load(pmag, prev_mag, lane);
     fft_packed(prv, cur, lane, T, xb, v);
     float lg0, lg1;
-    float fl = unpack_mag<true, true>(v, lane, T, pmag, logspec, lg0, lg1);
+    float fl = unpack_mag<true, true>(v, lane, T, pmag, logspec, lg0, lg1, []() {});
     mags_store(pmag, prev_mag, lane);
     fl = wave_sum(fl);
     if (lane == 0) flux_sum[0] = fl;
@@ -611,13 +619,19 @@ template <int C, bool LOG, bool BM, bool SAMPLES>
 int launch_stft(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int64_t* d_pos, int64_t frame_begin,
                 int n_frames, int hop, float* d_logspec, float* d_flux_sum, float* d_meanabs, float* d_samples,
                 float* d_bandmax, hipStream_t st) {
-    // frames per wave: long enough to amortise the 1-frame halo, short enough to fill 256 CUs
-    int fpw = 32;
-    const long waves_wanted = (long)ctx->num_cus * 12 * 2;
-    while (fpw > 4 && (long)(n_frames + fpw - 1) / fpw < waves_wanted) fpw >>= 1;
+    // frames per wave: the range is cut into k rounds of one wave per wave slot (2 per SIMD), k as small as keeps a
+    // wave at <= 64 frames: long chunks amortise the 1-frame halo, whole rounds leave no tail (216 000 frames: 53)
+    const long slots = (long)ctx->num_cus * 4 * AUR_STFT_WAVES_PER_SIMD;
+    const long rounds = (n_frames + slots * 64 - 1) / (slots * 64);
+    int fpw = (int)((n_frames + slots * rounds - 1) / (slots * rounds));
+    if (fpw < 4) fpw = 4;
     if (ctx->stft_fpw > 0) fpw = ctx->stft_fpw;
     const long n_waves = ((long)n_frames + fpw - 1) / fpw;
     const unsigned grid = (unsigned)((n_waves + kWavesPerWG - 1) / kWavesPerWG);
+    if (kLdsBytes > 64 * 1024) {   // once per instantiation and device would do; the call is cheap
+        AUR_CHECK_HIP(hipFuncSetAttribute((const void*)stft_frames_kernel<C, LOG, BM, SAMPLES>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    }
     hipLaunchKernelGGL((stft_frames_kernel<C, LOG, BM, SAMPLES>), dim3(grid), dim3(kWavesPerWG * 64), kLdsBytes, st,
                        d_audio, (long)n_samples, (const long*)d_pos, (long)frame_begin, n_frames, hop, fpw,
                        ctx->d_window, ctx->d_twid, d_logspec, d_flux_sum, d_meanabs, d_samples, d_bandmax);
@@ -661,7 +675,7 @@ extern "C" int aur_stft_frames(aur_ctx* ctx, const float* d_audio, int64_t n_sam
     AUR_REQUIRE(((uintptr_t)d_audio & 7u) == 0 &&
                     (d_samples == nullptr || ((uintptr_t)d_samples & 7u) == 0),
                 "aur_stft_frames: misaligned device pointer");
-    static_assert(kLdsBytes <= 64 * 1024, "dynamic LDS above 64 KB needs hipFuncSetAttribute");
+    static_assert(kLdsBytes <= 160 * 1024, "LDS of a CU");
     hipStream_t st = (hipStream_t)stream;
     if (channels == 2)
         return launch_stft_c<2>(ctx, d_audio, n_samples, d_pos, frame_begin, n_frames, hop, d_logspec, d_flux_sum,

@@ -23,7 +23,14 @@ if [ "$1" = build ]; then
                sed -i 's/(f + 1 < cend) ? f + 1 : -1, hop, lane, nxt);/fstart, hop, lane, nxt);/' $f ;;
       noload)  sed -i 's/(f + 1 < cend) ? f + 1 : -1, hop, lane, nxt);/fstart, hop, lane, nxt);/' $f ;;
     esac
-    make -s -C $d/aurora_amd/csrc OUT=../../lib_$v.so BUILD=build > /dev/null
+    extra=""
+    case $v in
+      w3)    extra="-DAUR_STFT_WAVES_PER_SIMD=3 -DAUR_STFT_WAVES_PER_WG=12 -DAUR_STFT_MID_AT=4" ;;
+      w3b)   extra="-DAUR_STFT_WAVES_PER_SIMD=3 -DAUR_STFT_WAVES_PER_WG=6 -DAUR_STFT_MID_AT=4" ;;
+      mid4)  extra="-DAUR_STFT_MID_AT=4" ;;
+      mid6)  extra="-DAUR_STFT_MID_AT=6" ;;
+    esac
+    make -s -C $d/aurora_amd/csrc OUT=../../lib_$v.so BUILD=build EXTRA="$extra" > /dev/null
     mv $d/lib_$v.so $OUT/ 2>/dev/null || mv $d/aurora_amd/lib_$v.so $OUT/ 2>/dev/null || true
     rm -rf $d
   done

@@ -241,6 +241,26 @@ __global__ __launch_bounds__(384) void envelope_vertices_kernel(const float* __r
     dst[1] = cy + cs360[2 * i + 1] * r;
 }
 
+// ---- "Waveform - Circular" -----------------------------------------------------------------------------------------
+// rt_widget.py:871-896 with n = 1024 samples: segs = min(720, n), step = max(1, int(n / segs)) = 1, so every sample is
+// a vertex: r = base_r + float(samples[i]) * amp, (x, y) = (cx + cos(a_i) r, cy + sin(a_i) r).  One thread per vertex.
+__global__ __launch_bounds__(256) void wave_circular_vertices_kernel(const float* __restrict__ samples,
+                                                                     const double* __restrict__ energy,
+                                                                     const double* __restrict__ cs, int W, int H,
+                                                                     double* __restrict__ verts) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;          // < AUR_BLOCK
+    const double mn = (double)(W < H ? W : H);
+    const double cx = (double)W / 2.0, cy = (double)H / 2.0;
+    const double base_r = mn * 0.28;                                        // :873
+    const double amp = mn * 0.22 * (0.5 + 0.6 * energy[f]);                 // :874
+    const double v = (double)samples[(long)f * AUR_BLOCK + i];              // :886
+    const double r = base_r + v * amp;                                      // :888
+    double* dst = verts + ((long)f * AUR_BLOCK + i) * 2;
+    dst[0] = cx + cs[2 * i] * r;                                            // :889
+    dst[1] = cy + cs[2 * i + 1] * r;                                        // :890
+}
+
 // ---- bit planes -------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ void or_span(uint32_t* row, int c0, int c1, int W) {
@@ -601,6 +621,22 @@ extern "C" int aur_envelope_vertices(aur_ctx* ctx, const float* d_logspec, const
     a.rot = p->rotation_rad;
     hipLaunchKernelGGL(envelope_vertices_kernel, dim3(n_frames), dim3(384), 0, (hipStream_t)stream, d_logspec, d_energy,
                        d_phase, a, d_cos_sin360, d_verts);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_wave_circular_vertices(aur_ctx* ctx, const float* d_samples, const double* d_energy, int n_frames,
+                                          const double* d_cos_sin, int W, int H, double* d_verts, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_wave_circular_vertices: n_frames %d outside [0, 65535]",
+                n_frames);
+    AUR_REQUIRE(W >= 16 && H >= 16, "aur_wave_circular_vertices: frame %dx%d too small", W, H);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_samples && d_energy && d_cos_sin && d_verts, "aur_wave_circular_vertices: null device pointer");
+    static_assert(AUR_BLOCK % 256 == 0, "one thread per sample");
+    hipLaunchKernelGGL(wave_circular_vertices_kernel, dim3(AUR_BLOCK / 256, n_frames), dim3(256), 0,
+                       (hipStream_t)stream, d_samples, d_energy, d_cos_sin, W, H, d_verts);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -49,7 +49,8 @@ def mode_kind(mode: str) -> str:
     return "particles"
 
 
-SUPPORTED_KINDS = ("spectrum_linear", "waveform_linear", "particles", "spectrum_radial")
+SUPPORTED_KINDS = ("spectrum_linear", "waveform_linear", "particles", "spectrum_radial", "waveform_circular")
+PLANE_KINDS = ("spectrum_radial", "waveform_circular")       # rendered through bit planes, not column spans
 
 
 @dataclass
@@ -106,6 +107,17 @@ def angle_table(n: int, rotation_deg: float) -> np.ndarray:
     out = np.empty((n + 1, 2), dtype=np.float64)
     for i in range(n + 1):
         a = 2.0 * np.pi * (i / n) - (np.pi / 2.0) + np.deg2rad(rotation_deg)
+        out[i, 0] = np.cos(a)
+        out[i, 1] = np.sin(a)
+    return out
+
+
+def wave_circular_angle_table(rotation_deg: float, n: int = BLOCK) -> np.ndarray:
+    """(cos a_i, sin a_i), a_i = 2 pi (i / max(1, n - 1)) - pi / 2 + deg2rad(rot), i < n (rt_widget.py:887), float64
+    [n, 2] with the reference's expression and scalar calls."""
+    out = np.empty((n, 2), dtype=np.float64)
+    for i in range(n):
+        a = 2.0 * np.pi * (i / max(1, n - 1)) - (np.pi / 2.0) + np.deg2rad(rotation_deg)
         out[i, 0] = np.cos(a)
         out[i, 1] = np.sin(a)
     return out
@@ -448,6 +460,43 @@ class HipExportEngine:
         if count is None:
             count = an.n_frames - first
         planes = self.radial_planes(prep, an, sc, W, H, first, count, planes_out)
+        return self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
+
+    # ------------------------------------------------------------------ Waveform - Circular
+    def wave_circular_vertices(self, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int,
+                               rotation_deg: float = 0.0):
+        """Closed path float64 [count, 1024, 2] of frames first .. first + count (rt_widget.py:871-896)."""
+        if an.samples is None:
+            raise ValueError("Waveform - Circular needs analyze(..., want_samples=True)")
+        key = ("wavecirc", float(rotation_deg))
+        if key not in self._col2samp:
+            self._col2samp[key] = self.torch.from_numpy(wave_circular_angle_table(rotation_deg)).to(self.device)
+        verts = self.empty((count, BLOCK, 2), self.torch.float64)
+        _lib.check(self.lib.aur_wave_circular_vertices(
+            self.ctx.handle, _ptr(an.samples[first:first + count]), _ptr(sc.energy[first:first + count]), count,
+            _ptr(self._col2samp[key]), W, H, _ptr(verts), self.stream()), "aur_wave_circular_vertices")
+        return verts
+
+    def wave_circular_planes(self, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int,
+                             rotation_deg: float = 0.0, planes_out=None):
+        """(stroke planes int32 [count, H, W32], all-zero disc plane [1, H, W32], True) for fill_planes."""
+        torch = self.torch
+        W32 = (W + 31) // 32
+        stroke = planes_out[0] if planes_out is not None else self.empty((count, H, W32), torch.int32)
+        verts = self.wave_circular_vertices(an, sc, W, H, first, count, rotation_deg)
+        _lib.check(self.lib.aur_mask_stroke_closed(self.ctx.handle, _ptr(verts), BLOCK, count, W, H, _ptr(stroke),
+                                                   self.stream()), "aur_mask_stroke_closed")
+        key = ("nodisc", W, H)
+        if key not in self._col2samp:
+            self._col2samp[key] = torch.zeros((1, H, W32), dtype=torch.int32, device=self.device)
+        return stroke, self._col2samp[key], True
+
+    def render_wave_circular(self, an: Analysis, sc: Scan, W: int, H: int, first: int = 0, count: int | None = None,
+                             rotation_deg: float = 0.0, out=None, planes_out=None):
+        """Frames uint8 [count, H, W, 3] of "Waveform - Circular" (paint_frame, rt_widget.py:821-852)."""
+        if count is None:
+            count = an.n_frames - first
+        planes = self.wave_circular_planes(an, sc, W, H, first, count, rotation_deg, planes_out)
         return self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
 
     # ------------------------------------------------------------------ streaming Analyzer step

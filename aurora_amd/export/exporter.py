@@ -144,7 +144,8 @@ class HipOffscreenRenderer:
         self.frame_begin, self.frame_end = max(0, f0), min(self.total_frames, f1)
         self._pipe = FramePipeline(self._eng, self._track, self.mode, self.width, self.height, self.sensitivity,
                                    self.frame_begin, self.frame_end,
-                                   batch_frames=view_state.get("hip_batch_frames"), radial=radial)
+                                   batch_frames=view_state.get("hip_batch_frames"), radial=radial,
+                                   rotation_deg=float(view_state.get("radial_rotation_deg", 0.0)))
         self._cache = None          # (first_frame, uint8 [n, H, W, 3] host array)
 
     # -- batched fast path used by Exporter._run_pipe ---------------------------------------------------

@@ -19,7 +19,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from .engine import HipExportEngine, RadialConfig, Track, mode_kind, SUPPORTED_KINDS
+from .engine import HipExportEngine, PLANE_KINDS, RadialConfig, Track, mode_kind, SUPPORTED_KINDS
 
 
 class NullSink:
@@ -70,7 +70,7 @@ class FramePipeline:
     def __init__(self, engine: HipExportEngine, track: Track, mode: str, width: int, height: int,
                  sensitivity: float = 1.0, frame_begin: int = 0, frame_end: int | None = None,
                  batch_frames: int | None = None, slots: int = 2, scan_params: _lib.ScanParams | None = None,
-                 radial: "RadialConfig | None" = None):
+                 radial: "RadialConfig | None" = None, rotation_deg: float = 0.0):
         self.eng = engine
         self.track = track
         self.mode = mode
@@ -87,6 +87,8 @@ class FramePipeline:
         self.params = scan_params or _lib.ScanParams.defaults(sensitivity)
         self.frame_bytes = self.W * self.H * 3
         self.radial = (radial or RadialConfig.from_view_state(None, sensitivity)) if self.kind == "spectrum_radial" else None
+        self.rotation_deg = float(rotation_deg)          # radial_rotation_deg, used by "Waveform - Circular" too
+        self.planes = self.kind in PLANE_KINDS
         self._analysed = None
         self._radial_prep = None
 
@@ -96,7 +98,7 @@ class FramePipeline:
             eng = self.eng
             state = eng.carried_state(self.track, self.frame_begin, self.params) if self.frame_begin > 0 else None
             n = self.frame_end - self.frame_begin
-            an = eng.analyze(self.track, self.frame_begin, n, want_samples=(self.kind == "waveform_linear"))
+            an = eng.analyze(self.track, self.frame_begin, n, want_samples=self.kind.startswith("waveform"))
             sc = eng.scan(an, self.params, state)
             if self.radial is not None:
                 rstate = eng.carried_radial_state(self.track, self.frame_begin, self.radial)
@@ -113,6 +115,9 @@ class FramePipeline:
         if self.radial is not None:
             return self.eng.render_radial(self._radial_prep, an, sc, self.W, self.H, first, count, out=out,
                                           planes_out=scratch)
+        if self.kind == "waveform_circular":
+            return self.eng.render_wave_circular(an, sc, self.W, self.H, first, count, self.rotation_deg, out=out,
+                                                 planes_out=scratch)
         return self.eng.render(self.mode, an, sc, self.W, self.H, first, count, out=out, spans_out=scratch)
 
     # ---- full pipeline: GPU -> pinned host ring -> sink --------------------------------------------------
@@ -125,7 +130,7 @@ class FramePipeline:
             return 0
         B, S = min(self.batch, n_total), self.slots
         dev_frames = [eng.empty((B, self.H, self.W, 3), torch.uint8) for _ in range(S)]
-        if self.radial is not None:
+        if self.planes:
             dev_spans = [eng.empty((2, B, self.H, (self.W + 31) // 32), torch.int32) for _ in range(S)]
         else:
             K = {"spectrum_linear": _lib.K_SPECTRUM, "particles": _lib.K_PARTICLES,
@@ -174,7 +179,7 @@ class FramePipeline:
                 if copied[slot] is not None:
                     cur.wait_event(copied[slot])           # device slot no longer being read by the copy engine
                 self._render(an, sc, done, n, out=dev_frames[slot][:n],
-                             scratch=dev_spans[slot][:, :n] if self.radial is not None else dev_spans[slot][:n])
+                             scratch=dev_spans[slot][:, :n] if self.planes else dev_spans[slot][:n])
                 rendered = torch.cuda.Event()
                 rendered.record(cur)
                 copy_stream.wait_event(rendered)

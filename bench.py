@@ -113,12 +113,14 @@ def main():
     F = track.total_frames
     kind = mode_kind(args.mode)
     radial = RadialConfig() if kind == "spectrum_radial" else None
+    circular = kind == "waveform_circular"
+    planes_mode = radial is not None or circular
     K = {"spectrum_linear": _lib.K_SPECTRUM, "particles": _lib.K_PARTICLES, "waveform_linear": _lib.K_WAVEFORM,
-         "spectrum_radial": 0}[kind]
+         "spectrum_radial": 0, "waveform_circular": 0}[kind]
     B = max(1, min(args.batch, F))
     slots = 2
     dev_frames = [eng.empty((B, H, W, 3), torch.uint8) for _ in range(slots)]
-    if radial is not None:
+    if planes_mode:
         dev_spans = [eng.empty((2, B, H, (W + 31) // 32), torch.int32) for _ in range(slots)]
     else:
         dev_spans = [eng.empty((B, K, W), torch.int32) for _ in range(slots)]
@@ -129,7 +131,7 @@ def main():
         if ev_stft is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        an = eng.analyze(track, want_samples=(kind == "waveform_linear"))
+        an = eng.analyze(track, want_samples=kind.startswith("waveform"))
         if ev_stft is not None:
             e1.record()
             ev_stft.append((e0, e1, F))
@@ -141,14 +143,15 @@ def main():
             s = i % slots
             if radial is not None:
                 planes = eng.radial_planes(prep, an, sc, W, H, done, n, planes_out=dev_spans[s][:, :n])
+            elif circular:
+                planes = eng.wave_circular_planes(an, sc, W, H, done, n, planes_out=dev_spans[s][:, :n])
             else:
                 spans, _ = eng.spans(kind, an, sc, W, H, done, n, out=dev_spans[s][:n])
-            if radial is None:
                 work = eng.summarize(spans, K, W, H)           # column summaries: their own small kernel
             if ev_fill is not None:                            # the events bracket the fill kernel alone
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if radial is not None:
+            if planes_mode:
                 eng.fill_planes(planes, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n])
             else:
                 eng.fill(spans, K, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n], work=work, work_ready=True)
@@ -190,15 +193,16 @@ def main():
     roof_stft = kernel_stats(ev_stft, stft_bytes)
     if roof is not None:
         lin = W % 16 == 0 and os.environ.get("AUR_FILL_MODE", "0") != "1"
-        roof["kernel"] = ("raster_fill_planes_kernel" if radial is not None else
+        roof["kernel"] = ("raster_fill_planes_kernel" if planes_mode else
                           f"raster_fill_lin_kernel<{K}>" if lin else f"raster_fill16_kernel<{K}>")
     if roof_stft is not None:
-        roof_stft["kernel"] = f"stft_frames_kernel<{track.channels}>"
+        roof_stft["kernel"] = (f"stft_frames_kernel<{track.channels}, log=true, bandmax=false, "
+                               f"samples={'true' if kind.startswith('waveform') else 'false'}>")
     try:                                               # per-launch HBM bytes from separate --pmc passes, if collected
         with open(args.traffic_json) as fh:
             tj = json.load(fh)
         key = f"{W}x{H}x{B}"
-        if roof is not None and radial is None and tj.get("raster_fill", {}).get("config") == key:
+        if roof is not None and not planes_mode and tj.get("raster_fill", {}).get("config") == key:
             roof["traffic"] = tj["raster_fill"]["hbm_bytes_per_launch"]
         if roof_stft is not None and tj.get("stft", {}).get("frames") == F:
             roof_stft["traffic"] = tj["stft"]["hbm_bytes_per_launch"]

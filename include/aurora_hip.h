@@ -214,6 +214,15 @@ int aur_envelope_vertices(aur_ctx* ctx, const float* d_logspec, const double* d_
                           int n_frames, const aur_envelope_params* params, const double* d_cos_sin360, int W, int H,
                           double* d_verts, void* stream);
 
+/* "Waveform - Circular" (`_draw_waveform`, circular branch, rt_widget.py:871-896): the closed path through all
+ * 1024 samples of a frame (segs = min(720, n), step = max(1, int(n / segs)) = 1),
+ *   r = 0.28 min(W,H) + float(samples[i]) * 0.22 min(W,H) (0.5 + 0.6 energy),  (x, y) = (W/2 + cos(a_i) r, H/2 + sin(a_i) r).
+ * d_samples: float32 [n_frames, 1024] (aur_stft_frames' d_samples); d_cos_sin: float64 [1024, 2] host table of
+ * (cos a_i, sin a_i), a_i = 2 pi (i / 1023) - pi/2 + deg2rad(rotation) (rt_widget.py:887).
+ * d_verts: float64 [n_frames, 1024, 2]; stroke it with aur_mask_stroke_closed (`p.drawPath(path)`, :902). */
+int aur_wave_circular_vertices(aur_ctx* ctx, const float* d_samples, const double* d_energy, int n_frames,
+                               const double* d_cos_sin, int W, int H, double* d_verts, void* stream);
+
 /* Bit planes: uint32 [n_frames, H, ceil(W/32)], bit (x & 31) of word (x >> 5) = pixel (x, row) is covered.
  * aur_mask_stroke_closed: width-2 BevelJoin stroke of the closed polygon through d_verts [F, n_vertices, 2]
  *   (`p.drawPath(path)` with the width-2 pen, rt_widget.py:975-981);
@@ -225,8 +234,9 @@ int aur_mask_stroke_closed(aur_ctx* ctx, const double* d_verts, int n_vertices, 
 int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
                      uint32_t* d_plane, void* stream);
 
-/* RGB24 frames of "Spectrum - Radial" (paint_frame, rt_widget.py:821-852): background (13,13,18), stroke plane in the
- * pen colour, disc plane in (30,30,40) on top.  W must be a multiple of 16.  disc_static != 0: d_disc_plane holds ONE
+/* RGB24 frames of "Spectrum - Radial" / "Waveform - Circular" (paint_frame, rt_widget.py:821-852): background
+ * (13,13,18), stroke plane in the pen colour, disc plane in (30,30,40) on top (an all-zero static plane when the mode
+ * has no disc).  W must be a multiple of 16.  disc_static != 0: d_disc_plane holds ONE
  * plane [H, ceil(W/32)] used for every frame (the envelope does not depend on the frame when edge_waviness and the
  * audio term are off, which is the export default). */
 int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, const uint32_t* d_disc_plane, int disc_static,

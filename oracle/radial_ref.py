@@ -12,9 +12,11 @@ Restates (paths relative to the reference root):
                              temporal EMA, which makes the path depend on every earlier frame)
 * ``envelope_path``       <- ``_draw_center_image_and_mask`` ``rt_widget.py:1004-1051`` (361-vertex clip path)
 * ``feather_ring_paths``  <- ``rt_widget.py:1098-1114``
+* ``wave_circular_path``  <- ``_draw_waveform`` circular branch ``rt_widget.py:871-896`` ("Waveform - Circular")
 
 Parity pin: ``tests/golden/drawlists_*.npz`` hold the ``drawPath`` and ``setClipPath`` vertices the reference
 itself produced for "Spectrum - Radial" (``tests/golden/make_golden.py``); ``tests/test_oracle_golden.py`` compares.
+``tests/golden/wavecirc_*.npz`` hold the ``drawPath`` vertices of "Waveform - Circular" the same way.
 Pixel coverage of these paths (``raster_ref.py``) is parity-unpinned against Qt, like the linear modes.
 """
 from __future__ import annotations
@@ -196,3 +198,21 @@ def feather_ring_paths(spectrum, energy, phase, w, h, p: RadialParams | None = N
             out[i, 1] = cy + np.sin(a) * r
         rings.append((out, max(10, 70 - 10 * k)))
     return rings
+
+
+def wave_circular_path(samples, energy, w, h, rotation_deg=0.0):
+    """Vertices float64[n_vertices, 2] of the closed path of "Waveform - Circular" (rt_widget.py:867-896; export
+    path: ``_offscreen_paint`` is True, so ``segs = min(720, n)`` whatever shadow / glow say)."""
+    n = len(samples)
+    cx, cy = w / 2.0, h / 2.0
+    base_r = min(w, h) * 0.28
+    amp = min(w, h) * 0.22 * (0.5 + 0.6 * energy)
+    segs = min(720, n)
+    step = max(1, int(n / segs))
+    out = []
+    for i in range(0, n, step):
+        v = float(samples[i])
+        a = 2.0 * np.pi * (i / max(1, n - 1)) - (np.pi / 2.0) + np.deg2rad(rotation_deg)
+        r = base_r + v * amp
+        out.append((cx + np.cos(a) * r, cy + np.sin(a) * r))
+    return np.asarray(out, dtype=np.float64)

@@ -435,3 +435,11 @@ def render_radial_frame(path_verts, env_verts, pen_rgb, w, h, bg=BG):
     frame[unpack_mask(stroke_mask_closed(path_verts, w, h), w)] = np.asarray(pen_rgb, dtype=np.uint8)
     frame[unpack_mask(polygon_mask(env_verts, w, h), w)] = np.asarray(DISC_RGB, dtype=np.uint8)
     return frame
+
+
+def render_wave_circular_frame(path_verts, pen_rgb, w, h, bg=BG):
+    """One "Waveform - Circular" frame (rt_widget.py:866-902): background and the stroked closed path."""
+    frame = np.empty((h, w, 3), dtype=np.uint8)
+    frame[:] = np.asarray(bg, dtype=np.uint8)
+    frame[unpack_mask(stroke_mask_closed(path_verts, w, h), w)] = np.asarray(pen_rgb, dtype=np.uint8)
+    return frame

@@ -333,7 +333,45 @@ def capture_radial_view_state(name, kind, n, sr, fps, size, frames, view_state, 
     print(f"radialvs_{name}: {len(out)} arrays")
 
 
+def capture_wave_circular(name, kind, n, sr, fps, sizes, frames, view_state, sensitivity=1.0):
+    """Waveform - Circular (rt_widget.py:871-902): the closed path handed to drawPath, per frame size."""
+    from export.exporter import QPainterOffscreenRenderer
+    audio = _track(kind, n, sr, 2)
+    path = f"mem://wc_{name}"
+    _AUDIO[path] = (audio, sr)
+    out = dict(audio=audio, sample_rate=sr, fps=fps, frames=np.asarray(frames), sizes=np.asarray(sizes),
+               sensitivity=sensitivity, view_state_json=np.asarray(__import__("json").dumps(view_state)))
+    keep = set(int(f) for f in frames)
+    for (w, h) in sizes:
+        r = QPainterOffscreenRenderer(w, h, "Waveform - Circular", (0.2, 0.8, 1.0), sensitivity, fps, path,
+                                      **view_state)
+        total = int(np.ceil(r.duration * fps))
+        for i in range(total):
+            s, spec = r._read_frame(i / fps)
+            img = r._view.render_frame_to_qimage(w, h, s, spec)
+            if i not in keep:
+                continue
+            calls = img.calls
+            key = f"{w}x{h}_f{i}"
+            sp = [c for c in calls if c[0] == "setPen"][0]
+            assert sp[2] == 2 and sp[3] == "SquareCap" and sp[4] == "BevelJoin", sp
+            dp = [c for c in calls if c[0] == "drawPath"]
+            assert len(dp) == 1 and dp[0][1][-1][0] == "Z"
+            out[key + "_pen"] = np.asarray(sp[1][:3], np.uint8)
+            out[key + "_path"] = _path_xy(dp[0][1])
+            out[key + "_calls"] = np.asarray([c[0] for c in calls])
+    np.savez_compressed(os.path.join(HERE, f"wavecirc_{name}.npz"), **out)
+    print(f"wavecirc_{name}: {len(out)} arrays")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "wave_circular":  # adds the wavecirc_* fixtures only
+        _install_stand_ins()
+        sys.path.insert(0, REF)
+        capture_wave_circular("pink_48k_60", "pink", 12000, 48000, 60, [(1280, 720), (3840, 2160)], [0, 1, 5, 14], {})
+        capture_wave_circular("sweep_44k1_30_rot", "sweep", 22050, 44100, 30, [(1000, 562)], [0, 3, 7],
+                              dict(radial_rotation_deg=33.0), sensitivity=1.7)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "radial_vs":      # adds the radialvs_* fixtures only
         _install_stand_ins()
         sys.path.insert(0, REF)

@@ -357,8 +357,8 @@ def test_worker_end_to_end_raw_stream(eng, tmp_path, capsys):
     track = eng.upload_track(audio, sr, fps)
     want = _np(FramePipeline(eng, track, "Spectrum - Linear", W, H).render_device()).tobytes()
     assert raw.read_bytes() == want
-    # unsupported mode -> exit 1 with an error message, as the reference reports export failures (worker.py:77-79)
-    cfg["mode"] = "Waveform - Circular"
+    # unsupported decoration -> exit 1 with an error message, as the reference reports export failures (worker.py:77-79)
+    cfg["view_state"] = {"hip_device": 0, "glow_enabled": True}
     cfgp.write_text(json.dumps(cfg))
     assert worker.main(["worker.py", str(cfgp)]) == 1
     assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["type"] == "error"
@@ -484,3 +484,66 @@ def test_radial_time_shards_byte_identical(eng):
         for a, b in zip(cuts[:-1], cuts[1:]):
             FramePipeline(eng, track, "Spectrum - Radial", W, H, frame_begin=a, frame_end=b, batch_frames=8).run(buf)
         assert buf.getvalue() == dev, nshards
+
+
+# ------------------------------------------------------------------ Waveform - Circular
+
+@pytest.mark.parametrize("fixture", ["wavecirc_pink_48k_60", "wavecirc_sweep_44k1_30_rot"])
+def test_wave_circular_vertices_vs_reference_paths(eng, fixture):
+    """GPU closed path of "Waveform - Circular" vs the vertices the reference handed to drawPath: bit-exact (samples,
+    energy and the angle table are exact, the vertex formula has no transcendental on the device)."""
+    import json
+    from aurora_amd import _lib
+    g = load_golden(fixture)
+    audio, sr, fps = g["audio"], int(g["sample_rate"]), int(g["fps"])
+    sens = float(g["sensitivity"])
+    rot = float(json.loads(str(g["view_state_json"])).get("radial_rotation_deg", 0.0))
+    track = eng.upload_track(audio, sr, fps)
+    an = eng.analyze(track, want_samples=True)
+    sc = eng.scan(an, _lib.ScanParams.defaults(sens))
+    pen = _np(sc.pen_rgb)[:, :3]
+    seen = 0
+    for (w, h) in g["sizes"]:
+        verts = _np(eng.wave_circular_vertices(an, sc, int(w), int(h), 0, an.n_frames, rot))
+        for f in g["frames"]:
+            key = f"{int(w)}x{int(h)}_f{int(f)}"
+            assert np.array_equal(verts[f], g[key + "_path"]), (key, float(np.max(np.abs(verts[f] - g[key + "_path"]))))
+            assert np.array_equal(pen[f], g[key + "_pen"])
+            seen += 1
+    assert seen > 0
+
+
+@pytest.mark.parametrize("size", [(640, 368), (1280, 720)])
+def test_wave_circular_raster_bit_exact(eng, size):
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    from oracle import radial_ref as RR
+    W, H = size
+    sr, fps = 48000, 60
+    audio = synth.pink(6000, 2, seed=9)
+    track = eng.upload_track(audio, sr, fps)
+    pipe = FramePipeline(eng, track, "Waveform - Circular", W, H, rotation_deg=12.5)
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    samples, energy, pen = _np(an.samples), _np(sc.energy), _np(sc.pen_rgb)[:, :3]
+    for f in range(an.n_frames):
+        path = RR.wave_circular_path(samples[f], float(energy[f]), W, H, 12.5)
+        want = R.render_wave_circular_frame(path, pen[f], W, H)
+        assert np.array_equal(frames[f], want), (size, f, int(np.sum(frames[f] != want)))
+    assert (frames[1] != np.array(R.BG, np.uint8)).any(axis=2).sum() > 2 * np.pi * 0.28 * H      # a ring was drawn
+
+
+def test_wave_circular_time_shards_byte_identical(eng):
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    import io
+    W, H, sr, fps = 640, 368, 48000, 60
+    audio = synth.pink(sr // 2 + 77, 2, seed=13)
+    track = eng.upload_track(audio, sr, fps)
+    F = track.total_frames
+    dev = _np(FramePipeline(eng, track, "Waveform - Circular", W, H).render_device()).tobytes()
+    cuts = [0, F // 3, F]
+    buf = io.BytesIO()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        FramePipeline(eng, track, "Waveform - Circular", W, H, frame_begin=a, frame_end=b, batch_frames=8).run(buf)
+    assert buf.getvalue() == dev

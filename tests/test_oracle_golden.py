@@ -197,3 +197,28 @@ def test_radial_view_state_paths_match_reference(fixture):
             assert np.array_equal(verts, g[key + "_rings"][k])
             assert tuple(fills[1 + k]) == (13, 13, 18, alpha)
     assert seen == len(g["frames"])
+
+
+@pytest.mark.parametrize("fixture", ["wavecirc_pink_48k_60", "wavecirc_sweep_44k1_30_rot"])
+def test_wave_circular_paths_match_reference(fixture):
+    """Waveform - Circular: the closed drawPath vertices of the reference (1024 per frame), incl. a rotated case."""
+    import json
+    from oracle import radial_ref as RR
+    g = load_golden(fixture)
+    audio, sr, fps = g["audio"], int(g["sample_rate"]), int(g["fps"])
+    sens = float(g["sensitivity"])
+    rot = float(json.loads(str(g["view_state_json"])).get("radial_rotation_deg", 0.0))
+    ref = A.analyze_track(audio, sr, fps, sensitivity=sens)
+    rgb, _ = A.amp_to_color_track(ref["energy"])
+    seen = 0
+    for (w, h) in g["sizes"]:
+        for f in g["frames"]:
+            key = f"{int(w)}x{int(h)}_f{int(f)}"
+            want = g[key + "_path"]
+            got = RR.wave_circular_path(ref["samples"][f], float(ref["energy"][f]), int(w), int(h), rot)
+            assert got.shape == want.shape == (1024, 2)
+            assert np.array_equal(got, want), (key, float(np.max(np.abs(got - want))))
+            assert np.array_equal(rgb[f], g[key + "_pen"])
+            assert list(g[key + "_calls"]) == ['fillRect', 'setPen', 'drawPath', 'end']
+            seen += 1
+    assert seen == len(g["sizes"]) * len(g["frames"])

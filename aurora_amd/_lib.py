@@ -24,6 +24,7 @@ SYMBOLS = (
     "aur_raster_work_bytes", "aur_span_summary", "aur_raster_spans_ws",
     "aur_radial_stage1", "aur_radial_ema", "aur_radial_vertices", "aur_envelope_vertices",
     "aur_wave_circular_vertices", "aur_mask_stroke_closed", "aur_mask_polygon", "aur_raster_planes",
+    "aur_rgb24_to_yuv420p",
     "aur_host_alloc", "aur_host_free", "aur_readback_async", "aur_stream_synchronize",
 )
 
@@ -113,6 +114,7 @@ def _declare(lib):
     lib.aur_envelope_vertices.argtypes = [vp, vp, vp, vp, i32, C.POINTER(EnvelopeParams), vp, i32, i32, vp, vp]
     lib.aur_wave_circular_vertices.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp]
     lib.aur_mask_stroke_closed.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.aur_rgb24_to_yuv420p.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     lib.aur_mask_polygon.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.aur_raster_planes.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp]
     lib.aur_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]

@@ -1,0 +1,90 @@
+// Wire format of the frames handed to FFmpeg (export/exporter.py:429-434: "-f rawvideo -pix_fmt rgb24 -s WxH").
+//
+// The reference pipes packed rgb24 (3 B per pixel) and lets FFmpeg's swscale convert to yuv420p for x264
+// (exporter.py:485-490 "-pix_fmt yuv420p").  Every exported frame crosses PCIe, which bounds the end-to-end rate far
+// below the HBM rate of the rasteriser, so the conversion can run on the GPU instead: planar yuv420p is 1.5 B per pixel,
+// half the readback bytes, and FFmpeg is then started with "-pix_fmt yuv420p" for its input.
+// This is opt-in (view_state["hip_wire_format"] = "yuv420p"): the default wire format stays the reference's rgb24.
+//
+// Conversion (stated in full because FFmpeg is not available to pin it; oracle/wire_ref.py restates it in numpy):
+// ITU-R BT.601, limited range, 8-bit integer form
+//     Y  = (( 66 R + 129 G +  25 B + 128) >> 8) + 16
+//     Cb = ((-38 R -  74 G + 112 B + 128) >> 8) + 128
+//     Cr = ((112 R -  94 G -  18 B + 128) >> 8) + 128          (>> is an arithmetic shift)
+// with Cb, Cr computed from the rounded mean (sum + 2) >> 2 of each 2x2 pixel block.  Bound: HBM (3 B read + 1.5 B
+// written per pixel, no reuse).
+#include "common.h"
+
+namespace {
+
+// One lane: 4 pixels x 2 rows.  A wave reads 768 contiguous bytes of each of the two rows (12 B per lane, dwordx3),
+// writes 256 contiguous bytes of each Y row and 128 contiguous bytes of the U and of the V row.
+__global__ __launch_bounds__(256) void rgb24_to_yuv420p_kernel(const uint8_t* __restrict__ rgb, int W, int H,
+                                                               uint8_t* __restrict__ yuv) {
+    const int f = blockIdx.z;
+    const int y2 = blockIdx.y;                                   // row pair
+    const int x4 = blockIdx.x * 256 + threadIdx.x;               // group of 4 pixels
+    if (x4 * 4 >= W) return;
+    const size_t frame_px = (size_t)W * H;
+    const uint8_t* src = rgb + (size_t)f * frame_px * 3 + ((size_t)(2 * y2) * W + 4 * x4) * 3;
+    uint8_t* dst = yuv + (size_t)f * (frame_px + frame_px / 2);
+    struct __attribute__((aligned(4))) u3 {
+        uint32_t a, b, c;
+    };
+    const u3 r0 = *reinterpret_cast<const u3*>(src);
+    const u3 r1 = *reinterpret_cast<const u3*>(src + (size_t)W * 3);
+    uint32_t yw[2];
+    int sr[2] = {0, 0}, sg[2] = {0, 0}, sb[2] = {0, 0};         // 2x2 block sums, blocks 0 and 1 of this lane
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+        const u3 q = row ? r1 : r0;
+        const uint32_t w[3] = {q.a, q.b, q.c};
+        uint32_t out = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            auto byte_at = [&](int i) { return (int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu); };
+            const int R = byte_at(3 * p), G = byte_at(3 * p + 1), B = byte_at(3 * p + 2);
+            const int Y = ((66 * R + 129 * G + 25 * B + 128) >> 8) + 16;
+            out |= (uint32_t)Y << (8 * p);
+            sr[p >> 1] += R;
+            sg[p >> 1] += G;
+            sb[p >> 1] += B;
+        }
+        yw[row] = out;
+    }
+    uint32_t* ydst = reinterpret_cast<uint32_t*>(dst + (size_t)(2 * y2) * W + 4 * x4);
+    ydst[0] = yw[0];
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ydst) + W) = yw[1];
+    uint32_t u = 0, v = 0;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int R = (sr[b] + 2) >> 2, G = (sg[b] + 2) >> 2, B = (sb[b] + 2) >> 2;
+        const int Cb = ((-38 * R - 74 * G + 112 * B + 128) >> 8) + 128;
+        const int Cr = ((112 * R - 94 * G - 18 * B + 128) >> 8) + 128;
+        u |= (uint32_t)Cb << (8 * b);
+        v |= (uint32_t)Cr << (8 * b);
+    }
+    const size_t coff = (size_t)y2 * (W / 2) + 2 * x4;
+    *reinterpret_cast<uint16_t*>(dst + frame_px + coff) = (uint16_t)u;
+    *reinterpret_cast<uint16_t*>(dst + frame_px + frame_px / 4 + coff) = (uint16_t)v;
+}
+
+}  // namespace
+
+extern "C" int aur_rgb24_to_yuv420p(aur_ctx* ctx, const uint8_t* d_rgb, int n_frames, int W, int H, uint8_t* d_yuv,
+                                    void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_rgb24_to_yuv420p: n_frames %d outside [0, 65535]", n_frames);
+    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_rgb24_to_yuv420p: frame size %dx%d unsupported", W,
+                H);
+    AUR_REQUIRE(W % 4 == 0 && H % 2 == 0, "aur_rgb24_to_yuv420p: %dx%d: width must be a multiple of 4, height even", W, H);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_rgb && d_yuv, "aur_rgb24_to_yuv420p: null device pointer");
+    AUR_REQUIRE(((uintptr_t)d_rgb & 3u) == 0 && ((uintptr_t)d_yuv & 3u) == 0,
+                "aur_rgb24_to_yuv420p: device pointers must be 4-byte aligned");
+    hipLaunchKernelGGL(rgb24_to_yuv420p_kernel, dim3((W / 4 + 255) / 256, H / 2, n_frames), dim3(256), 0,
+                       (hipStream_t)stream, d_rgb, W, H, d_yuv);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}

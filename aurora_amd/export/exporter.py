@@ -145,7 +145,9 @@ class HipOffscreenRenderer:
         self._pipe = FramePipeline(self._eng, self._track, self.mode, self.width, self.height, self.sensitivity,
                                    self.frame_begin, self.frame_end,
                                    batch_frames=view_state.get("hip_batch_frames"), radial=radial,
-                                   rotation_deg=float(view_state.get("radial_rotation_deg", 0.0)))
+                                   rotation_deg=float(view_state.get("radial_rotation_deg", 0.0)),
+                                   wire_format=str(view_state.get("hip_wire_format", "rgb24")))
+        self.wire_format = self._pipe.wire_format
         self._cache = None          # (first_frame, uint8 [n, H, W, 3] host array)
 
     # -- batched fast path used by Exporter._run_pipe ---------------------------------------------------
@@ -260,8 +262,12 @@ def list_gpu_export_devices() -> List[Dict[str, str]]:
 
 
 def build_ffmpeg_cmd(width: int, height: int, fps: int, out_path: str, audio_path: str,
-                     prefer_hevc: bool = False, gpu_device: Optional[str] = None) -> Tuple[List[str], str]:
-    """FFmpeg argv for rawvideo rgb24 WxH@fps on stdin + the audio file (exporter.py:413-491)."""
+                     prefer_hevc: bool = False, gpu_device: Optional[str] = None,
+                     input_pix_fmt: str = "rgb24") -> Tuple[List[str], str]:
+    """FFmpeg argv for rawvideo WxH@fps on stdin + the audio file (exporter.py:413-491).  ``input_pix_fmt`` is the
+    reference's "rgb24" unless the renderer was asked for the yuv420p wire format (view_state["hip_wire_format"])."""
+    if input_pix_fmt not in ("rgb24", "yuv420p"):
+        raise ValueError(f"input_pix_fmt {input_pix_fmt!r}")
     out_path = _ensure_ext(out_path, ".mp4")
     ffmpeg = _ffmpeg_bin()
     enc = _ffmpeg_encoders(ffmpeg)
@@ -274,7 +280,7 @@ def build_ffmpeg_cmd(width: int, height: int, fps: int, out_path: str, audio_pat
         choices = list_gpu_export_devices()
         dev = choices[0]["id"] if choices else ""
 
-    argv: List[str] = [ffmpeg, "-y", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{width}x{height}",
+    argv: List[str] = [ffmpeg, "-y", "-f", "rawvideo", "-pix_fmt", input_pix_fmt, "-s", f"{width}x{height}",
                        "-r", str(int(fps)), "-i", "pipe:0", "-i", audio_path]
     fam = dev.split(":", 1)[0] if dev else ""
     arg = dev.split(":", 1)[1] if ":" in dev else ""
@@ -302,7 +308,7 @@ def build_ffmpeg_cmd(width: int, height: int, fps: int, out_path: str, audio_pat
     if vfilter:
         argv += ["-vf", vfilter]
     argv += ["-c:v", codec, *vflags, "-pix_fmt", pix_out, "-c:a", "aac", "-b:a", "192k", "-shortest", out_path]
-    return argv, "rgb24"
+    return argv, input_pix_fmt
 
 
 # ----------------------------------------------------------------------------- exporter
@@ -339,7 +345,8 @@ class Exporter:
         renderer = self.make_renderer()
         logger.info("Export using HIP renderer on MI355X (device %s)", self.view_state.get("hip_device", 0))
         cmd, _ = build_ffmpeg_cmd(self.width, self.height, self.fps, out_path, self.audio_path,
-                                  prefer_hevc=self.prefer_hevc, gpu_device=self.gpu_device)
+                                  prefer_hevc=self.prefer_hevc, gpu_device=self.gpu_device,
+                                  input_pix_fmt=getattr(renderer, "wire_format", "rgb24"))
         return self._run_pipe(renderer, cmd, progress_cb=progress_cb)
 
     def render_to_sink(self, sink, progress_cb=None):

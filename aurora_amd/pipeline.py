@@ -70,7 +70,7 @@ class FramePipeline:
     def __init__(self, engine: HipExportEngine, track: Track, mode: str, width: int, height: int,
                  sensitivity: float = 1.0, frame_begin: int = 0, frame_end: int | None = None,
                  batch_frames: int | None = None, slots: int = 2, scan_params: _lib.ScanParams | None = None,
-                 radial: "RadialConfig | None" = None, rotation_deg: float = 0.0):
+                 radial: "RadialConfig | None" = None, rotation_deg: float = 0.0, wire_format: str = "rgb24"):
         self.eng = engine
         self.track = track
         self.mode = mode
@@ -85,7 +85,14 @@ class FramePipeline:
         self.batch = int(batch_frames or default_batch_frames(self.W, self.H))
         self.slots = int(max(1, slots))
         self.params = scan_params or _lib.ScanParams.defaults(sensitivity)
-        self.frame_bytes = self.W * self.H * 3
+        if wire_format not in ("rgb24", "yuv420p"):
+            raise ValueError(f"wire_format {wire_format!r}: expected 'rgb24' (the reference's, exporter.py:429-434) or 'yuv420p'")
+        if wire_format == "yuv420p" and (self.W % 4 or self.H % 2):
+            raise ValueError("yuv420p wire format needs a width that is a multiple of 4 and an even height")
+        self.wire_format = wire_format
+        self.rgb_bytes = self.W * self.H * 3
+        # bytes per frame on the wire (readback, sink)
+        self.frame_bytes = self.rgb_bytes if wire_format == "rgb24" else self.rgb_bytes // 2
         self.radial = (radial or RadialConfig.from_view_state(None, sensitivity)) if self.kind == "spectrum_radial" else None
         self.rotation_deg = float(rotation_deg)          # radial_rotation_deg, used by "Waveform - Circular" too
         self.planes = self.kind in PLANE_KINDS
@@ -130,6 +137,8 @@ class FramePipeline:
             return 0
         B, S = min(self.batch, n_total), self.slots
         dev_frames = [eng.empty((B, self.H, self.W, 3), torch.uint8) for _ in range(S)]
+        yuv = self.wire_format == "yuv420p"
+        dev_wire = [eng.empty((B, self.frame_bytes), torch.uint8) for _ in range(S)] if yuv else dev_frames
         if self.planes:
             dev_spans = [eng.empty((2, B, self.H, (self.W + 31) // 32), torch.int32) for _ in range(S)]
         else:
@@ -180,10 +189,14 @@ class FramePipeline:
                     cur.wait_event(copied[slot])           # device slot no longer being read by the copy engine
                 self._render(an, sc, done, n, out=dev_frames[slot][:n],
                              scratch=dev_spans[slot][:, :n] if self.planes else dev_spans[slot][:n])
+                if yuv:
+                    _lib.check(eng.lib.aur_rgb24_to_yuv420p(
+                        eng.ctx.handle, C.c_void_p(dev_frames[slot].data_ptr()), n, self.W, self.H,
+                        C.c_void_p(dev_wire[slot].data_ptr()), eng.stream()), "aur_rgb24_to_yuv420p")
                 rendered = torch.cuda.Event()
                 rendered.record(cur)
                 copy_stream.wait_event(rendered)
-                _lib.check(eng.lib.aur_readback_async(eng.ctx.handle, C.c_void_p(dev_frames[slot].data_ptr()),
+                _lib.check(eng.lib.aur_readback_async(eng.ctx.handle, C.c_void_p(dev_wire[slot].data_ptr()),
                                                       n * self.frame_bytes, host[slot].ptr,
                                                       C.c_void_p(copy_stream.cuda_stream)), "aur_readback_async")
                 ev = torch.cuda.Event()

@@ -209,17 +209,23 @@ def main():
     except (OSError, ValueError):
         pass
 
-    pcie_fps = None
+    pcie_fps = pcie_yuv_fps = None
     if args.pcie_frames > 0 and rank == 0:
         nf = min(F, args.pcie_frames)
-        pipe = FramePipeline(eng, track, args.mode, W, H, frame_begin=0, frame_end=nf, batch_frames=min(64, nf),
-                             slots=3)
-        pipe.analyse()
-        sink = NullSink()
-        torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        pipe.run(sink)
-        pcie_fps = nf / (time.perf_counter() - t1)
+        for wire in ("rgb24", "yuv420p"):          # the reference's wire format, then the opt-in 1.5 B/px one
+            pipe = FramePipeline(eng, track, args.mode, W, H, frame_begin=0, frame_end=nf, batch_frames=min(64, nf),
+                                 slots=3, wire_format=wire)
+            pipe.analyse()
+            sink = NullSink()
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            pipe.run(sink)
+            fps_w = nf / (time.perf_counter() - t1)
+            assert sink.bytes == nf * pipe.frame_bytes
+            if wire == "rgb24":
+                pcie_fps = fps_w
+            else:
+                pcie_yuv_fps = fps_w
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
@@ -239,6 +245,7 @@ def main():
             "stft_gbs": roof_stft["achieved"] if roof_stft else None,
             "roofline": roof, "roofline_stft": roof_stft, "cpu_baseline": cpu,
             "pcie_inclusive_fps": round(pcie_fps, 1) if pcie_fps else None,
+            "pcie_inclusive_fps_yuv420p": round(pcie_yuv_fps, 1) if pcie_yuv_fps else None,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -242,6 +242,16 @@ int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_
 int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, const uint32_t* d_disc_plane, int disc_static,
                       const uint8_t* d_pen_rgb /*[F,4]*/, int n_frames, int W, int H, uint8_t* d_frames, void* stream);
 
+/* ---- wire format ------------------------------------------------------------------------------- */
+
+/* Opt-in planar yuv420p wire format: the reference pipes rgb24 into FFmpeg
+ * (export/exporter.py:429-434) and FFmpeg's swscale converts to yuv420p (:485-490); converting on the GPU halves the
+ * bytes that cross PCIe and the pipe (1.5 instead of 3 per pixel).  BT.601 limited range, 8-bit integer form, chroma
+ * from the rounded 2x2 mean (csrc/wire.hip states the formula; swscale's own rounding is parity-unpinned).
+ * d_rgb: [F, H, W, 3]; d_yuv: [F, W*H*3/2] = Y [H, W], Cb [H/2, W/2], Cr [H/2, W/2] per frame.
+ * W must be a multiple of 4 and H even. */
+int aur_rgb24_to_yuv420p(aur_ctx* ctx, const uint8_t* d_rgb, int n_frames, int W, int H, uint8_t* d_yuv, void* stream);
+
 /* ---- readback ---------------------------------------------------------------------------------- */
 
 /* Pinned host memory for the frame ring that feeds the FFmpeg pipe (replaces the arr.copy()/tobytes()

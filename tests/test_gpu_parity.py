@@ -547,3 +547,48 @@ def test_wave_circular_time_shards_byte_identical(eng):
     for a, b in zip(cuts[:-1], cuts[1:]):
         FramePipeline(eng, track, "Waveform - Circular", W, H, frame_begin=a, frame_end=b, batch_frames=8).run(buf)
     assert buf.getvalue() == dev
+
+
+# ------------------------------------------------------------------ wire format
+
+@pytest.mark.parametrize("size", [(320, 192), (1280, 720), (1000, 562)])
+def test_yuv420p_wire_format_bit_exact(eng, size):
+    """aur_rgb24_to_yuv420p == oracle/wire_ref.py on rendered frames and on random bytes."""
+    import ctypes as C
+    import torch
+    from aurora_amd import _lib
+    from oracle import wire_ref as WR
+    W, H = size
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, size=(3, H, W, 3), dtype=np.uint8)
+    rgb[1] = 255
+    rgb[2, :, :, :] = (13, 13, 18)
+    d_rgb = torch.from_numpy(rgb).to(eng.device)
+    d_yuv = torch.zeros((3, W * H * 3 // 2), dtype=torch.uint8, device=eng.device)
+    _lib.check(eng.lib.aur_rgb24_to_yuv420p(eng.ctx.handle, C.c_void_p(d_rgb.data_ptr()), 3, W, H,
+                                            C.c_void_p(d_yuv.data_ptr()), eng.stream()), "aur_rgb24_to_yuv420p")
+    got = _np(d_yuv)
+    for f in range(3):
+        assert np.array_equal(got[f], WR.rgb24_to_yuv420p(rgb[f])), (size, f)
+    assert got[1].min() == 235 or got[1][:W * H].min() == 235       # white -> Y 235, limited range
+
+
+def test_pipeline_yuv420p_stream(eng):
+    """The opt-in wire format through the pinned ring: every frame of the stream is the conversion of the rgb24 one."""
+    import io
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    from oracle import wire_ref as WR
+    W, H, sr, fps = 320, 192, 48000, 60
+    audio = synth.pink(sr // 4, 2, seed=3)
+    track = eng.upload_track(audio, sr, fps)
+    rgb = _np(FramePipeline(eng, track, "Spectrum - Linear", W, H).render_device())
+    buf = io.BytesIO()
+    pipe = FramePipeline(eng, track, "Spectrum - Linear", W, H, batch_frames=4, wire_format="yuv420p")
+    n = pipe.run(buf)
+    raw = np.frombuffer(buf.getvalue(), np.uint8).reshape(n, W * H * 3 // 2)
+    assert n == rgb.shape[0]
+    for f in range(n):
+        assert np.array_equal(raw[f], WR.rgb24_to_yuv420p(rgb[f])), f
+    with pytest.raises(ValueError):
+        FramePipeline(eng, track, "Spectrum - Linear", 322, H, wire_format="yuv420p")

@@ -241,6 +241,58 @@ __global__ __launch_bounds__(384) void envelope_vertices_kernel(const float* __r
     dst[1] = cy + cs360[2 * i + 1] * r;
 }
 
+// Feather rings (:1098-1114): six scaled copies k = 1..6 of the path
+//   r = (inner + amp_noise sin(2 a + phase) + amp_audio spec_norm[si]) * (1 + 0.015 k)
+// (a plain sine instead of the fbm, no tanh limit).  Block = one frame, thread = one vertex; rings [F, 6, 361, 2].
+__global__ __launch_bounds__(384) void feather_ring_vertices_kernel(const float* __restrict__ logspec,
+                                                                    const double* __restrict__ energy,
+                                                                    const double* __restrict__ phase, EnvArgs a,
+                                                                    const double* __restrict__ cs360,
+                                                                    double* __restrict__ rings) {
+    __shared__ float s_red[8];
+    const int f = blockIdx.x;
+    const float* spec = logspec + (long)f * AUR_NBINS;
+    const double mn = (double)(a.W < a.H ? a.W : a.H);
+    const double cx = (double)a.W / 2.0, cy = (double)a.H / 2.0;
+    const double inner = mn * 0.22;
+    float mxv = 0.0f;
+    if (a.audio_amt != 0.0) {
+        float m = -INFINITY;
+        for (int i = threadIdx.x; i < AUR_NBINS; i += blockDim.x) m = fmaxf(m, spec[i]);
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        mxv = s_red[0];
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) mxv = fmaxf(mxv, s_red[k]);
+    }
+    const float mx = (mxv > 1e-9f) ? mxv : 1.0f;
+    const double amp_noise_px = mn * 0.025 * a.noise_amt;
+    const double energy_feather = fmin(1.0, energy[f] * a.sens_ratio);
+    const double amp_audio_px = mn * 0.06 * a.audio_amt * (0.4 + 0.6 * energy_feather);
+    const int i = threadIdx.x;
+    if (i > 360) return;
+    const int nlen = a.mirror ? 2 * AUR_NBINS - 2 : AUR_NBINS;
+    double s_val = 0.0;
+    if (a.audio_amt != 0.0) {
+        int si = (int)(((double)i / 360.0) * (double)(nlen - 1));
+        if (si >= AUR_NBINS) si = 2 * AUR_NBINS - 2 - si;
+        s_val = (double)__fdiv_rn(spec[si], mx);
+    }
+    double sn = 0.0;
+    if (amp_noise_px != 0.0) {
+        const double ang = 2.0 * 3.141592653589793 * ((double)i / 360.0) - (3.141592653589793 / 2.0) + a.rot;
+        sn = sin(ang * 2.0 + phase[f]);
+    }
+    const double r0 = inner + amp_noise_px * sn + amp_audio_px * s_val;                 // :1107
+    for (int k = 1; k <= 6; ++k) {
+        const double r = r0 * (1.0 + 0.015 * (double)k);
+        double* dst = rings + (((long)f * 6 + (k - 1)) * 361 + i) * 2;
+        dst[0] = cx + cs360[2 * i] * r;
+        dst[1] = cy + cs360[2 * i + 1] * r;
+    }
+}
+
 // ---- "Waveform - Circular" -----------------------------------------------------------------------------------------
 // rt_widget.py:871-896 with n = 1024 samples: segs = min(720, n), step = max(1, int(n / segs)) = 1, so every sample is
 // a vertex: r = base_r + float(samples[i]) * amp, (x, y) = (cx + cos(a_i) r, cy + sin(a_i) r).  One thread per vertex.
@@ -625,6 +677,47 @@ extern "C" int aur_envelope_vertices(aur_ctx* ctx, const float* d_logspec, const
     return AUR_OK;
 }
 
+// ---- feather blend ------------------------------------------------------------------------------------------------
+// `p.fillPath(feather_path, col)` for k = 1..6 with col = QColor(13, 13, 18, max(10, 70 - 10 k)) (:1099-1117), no
+// antialiasing (the hint was restored off at :1096): source-over of a constant translucent colour wherever ring k
+// covers a pixel centre.  Arithmetic = Qt's premultiplied ARGB32 source-over,
+//   d' = div255(c a) + div255(d (255 - a)),   div255(x) = (x + (x >> 8) + 0x80) >> 8      (parity-unpinned vs Qt).
+// One thread per 32-pixel word of a row: reads the six ring words, returns when none is set (most of the frame).
+__device__ __forceinline__ uint32_t div255(uint32_t x) { return (x + (x >> 8) + 0x80u) >> 8; }
+
+__global__ __launch_bounds__(256) void feather_blend_kernel(const uint32_t* __restrict__ ring_planes, int W, int H,
+                                                            int W32, uint8_t* __restrict__ frames) {
+    const int f = blockIdx.z, row = blockIdx.y;
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= W32) return;
+    uint32_t m[6], any = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        m[k] = ring_planes[(((size_t)f * 6 + k) * H + row) * W32 + w];
+        any |= m[k];
+    }
+    if (any == 0) return;
+    const uint32_t bg[3] = {13u, 13u, 18u};                                  // :1099
+    uint8_t* px = frames + (((size_t)f * H + row) * W + (size_t)w * 32) * 3;
+    while (any) {
+        const int b = __builtin_ctz(any);
+        any &= any - 1;
+        if (w * 32 + b >= W) break;
+        uint32_t c[3] = {px[3 * b], px[3 * b + 1], px[3 * b + 2]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if ((m[k] >> b) & 1u) {
+                const uint32_t a = (uint32_t)max(10, 70 - 10 * (k + 1));     // :1116
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) c[ch] = div255(bg[ch] * a) + div255(c[ch] * (255u - a));
+            }
+        }
+        px[3 * b] = (uint8_t)c[0];
+        px[3 * b + 1] = (uint8_t)c[1];
+        px[3 * b + 2] = (uint8_t)c[2];
+    }
+}
+
 extern "C" int aur_wave_circular_vertices(aur_ctx* ctx, const float* d_samples, const double* d_energy, int n_frames,
                                           const double* d_cos_sin, int W, int H, double* d_verts, void* stream) {
     int rc = aur_use_device(ctx);
@@ -637,6 +730,47 @@ extern "C" int aur_wave_circular_vertices(aur_ctx* ctx, const float* d_samples, 
     static_assert(AUR_BLOCK % 256 == 0, "one thread per sample");
     hipLaunchKernelGGL(wave_circular_vertices_kernel, dim3(AUR_BLOCK / 256, n_frames), dim3(256), 0,
                        (hipStream_t)stream, d_samples, d_energy, d_cos_sin, W, H, d_verts);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_feather_ring_vertices(aur_ctx* ctx, const float* d_logspec, const double* d_energy,
+                                        const double* d_phase, int n_frames, const aur_envelope_params* p,
+                                        const double* d_cos_sin360, int W, int H, double* d_rings, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(p != nullptr, "aur_feather_ring_vertices: null params");
+    AUR_REQUIRE(n_frames >= 0, "aur_feather_ring_vertices: n_frames %d < 0", n_frames);
+    AUR_REQUIRE(W >= 16 && H >= 16, "aur_feather_ring_vertices: frame %dx%d too small", W, H);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_logspec && d_energy && d_phase && d_cos_sin360 && d_rings,
+                "aur_feather_ring_vertices: null device pointer");
+    EnvArgs a;
+    a.mirror = p->radial_mirror ? 1 : 0;
+    a.W = W;
+    a.H = H;
+    a.noise_amt = (double)p->edge_waviness / 100.0;
+    a.audio_amt = p->feather_audio_enabled ? (double)p->feather_audio_amount / 100.0 : 0.0;
+    a.sens_ratio = p->feather_sensitivity / fmax(1e-3, p->waveform_sensitivity);
+    a.rot = p->rotation_rad;
+    hipLaunchKernelGGL(feather_ring_vertices_kernel, dim3(n_frames), dim3(384), 0, (hipStream_t)stream, d_logspec,
+                       d_energy, d_phase, a, d_cos_sin360, d_rings);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_feather_blend(aur_ctx* ctx, const uint32_t* d_ring_planes, int n_frames, int W, int H,
+                                 uint8_t* d_frames, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535 / 6, "aur_feather_blend: n_frames %d outside [0, %d]", n_frames,
+                65535 / 6);
+    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_feather_blend: frame size %dx%d unsupported", W, H);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_ring_planes && d_frames, "aur_feather_blend: null device pointer");
+    const int W32 = (W + 31) / 32;
+    hipLaunchKernelGGL(feather_blend_kernel, dim3((W32 + 255) / 256, H, n_frames), dim3(256), 0, (hipStream_t)stream,
+                       d_ring_planes, W, H, W32, d_frames);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -357,8 +357,6 @@ class HipExportEngine:
         """Ring values of every analysed frame (stage 1 + temporal EMA).  state: None at track start, else the
         float64 [L1] EMA state carried from the frames before ``an.frame_begin``."""
         torch = self.torch
-        if cfg.feather_enabled:
-            raise NotImplementedError("feather rings (view_state['feather_enabled']) are not implemented on the HIP path")
         F, L1 = an.n_frames, cfg.L1
         vals1 = self.empty((F, L1), torch.float64)
         h, st = self.ctx.handle, self.stream()
@@ -405,11 +403,39 @@ class HipExportEngine:
         return (self.radial_path_vertices(prep, sc, W, H, first, count),
                 self._envelope(prep, an, sc, W, H, first, count))
 
+    @staticmethod
+    def _envelope_params(cfg: RadialConfig):
+        return _lib.EnvelopeParams(int(cfg.radial_mirror), int(cfg.edge_waviness), int(cfg.feather_audio_enabled),
+                                   int(cfg.feather_audio_amount), float(cfg.feather_sensitivity),
+                                   float(cfg.waveform_sensitivity), float(np.deg2rad(cfg.radial_rotation_deg)))
+
+    def feather_ring_vertices(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int):
+        """Feather ring paths float64 [count, 6, 361, 2] (rt_widget.py:1098-1114)."""
+        ep = self._envelope_params(prep.cfg)
+        rings = self.empty((count, 6, 361, 2), self.torch.float64)
+        _lib.check(self.lib.aur_feather_ring_vertices(
+            self.ctx.handle, _ptr(an.logspec[first:first + count]), _ptr(sc.energy[first:first + count]),
+            _ptr(sc.phase[first:first + count]), count, C.byref(ep), _ptr(prep.cos_sin360), W, H, _ptr(rings),
+            self.stream()), "aur_feather_ring_vertices")
+        return rings
+
+    def feather_blend(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int, frames):
+        """Blends the six translucent rings of frames first .. first + count into ``frames`` (in place)."""
+        h, st = self.ctx.handle, self.stream()
+        W32 = (W + 31) // 32
+        step = 65535 // 6
+        for off in range(0, count, step):
+            n = min(step, count - off)
+            rings = self.feather_ring_vertices(prep, an, sc, W, H, first + off, n)
+            planes = self.empty((n, 6, H, W32), self.torch.int32)
+            _lib.check(self.lib.aur_mask_polygon(h, _ptr(rings), 361, 6 * n, W, H, _ptr(planes), st), "aur_mask_polygon")
+            _lib.check(self.lib.aur_feather_blend(h, _ptr(planes), n, W, H, _ptr(frames[off:off + n]), st),
+                       "aur_feather_blend")
+        return frames
+
     def _envelope(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int):
         cfg = prep.cfg
-        ep = _lib.EnvelopeParams(int(cfg.radial_mirror), int(cfg.edge_waviness), int(cfg.feather_audio_enabled),
-                                 int(cfg.feather_audio_amount), float(cfg.feather_sensitivity),
-                                 float(cfg.waveform_sensitivity), float(np.deg2rad(cfg.radial_rotation_deg)))
+        ep = self._envelope_params(cfg)
         env = self.empty((count, 361, 2), self.torch.float64)
         _lib.check(self.lib.aur_envelope_vertices(
             self.ctx.handle, _ptr(an.logspec[first:first + count]), _ptr(sc.energy[first:first + count]),
@@ -460,7 +486,10 @@ class HipExportEngine:
         if count is None:
             count = an.n_frames - first
         planes = self.radial_planes(prep, an, sc, W, H, first, count, planes_out)
-        return self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
+        out = self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
+        if prep.cfg.feather_enabled:
+            self.feather_blend(prep, an, sc, W, H, first, count, out)
+        return out
 
     # ------------------------------------------------------------------ Waveform - Circular
     def wave_circular_vertices(self, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int,

@@ -122,8 +122,7 @@ class HipOffscreenRenderer:
         kind = mode_kind(self.mode)
         if kind not in SUPPORTED_KINDS:
             raise NotImplementedError(f"mode {self.mode!r} is not implemented on the HIP export path yet")
-        for key in ("background_path", "glow_enabled", "shadow_enabled", "radial_fill_enabled", "center_image_path",
-                    "feather_enabled"):
+        for key in ("background_path", "glow_enabled", "shadow_enabled", "radial_fill_enabled", "center_image_path"):
             if view_state.get(key):
                 raise NotImplementedError(f"view_state[{key!r}] is not implemented on the HIP export path yet")
         radial = RadialConfig.from_view_state(view_state, self.sensitivity) if kind == "spectrum_radial" else None

@@ -214,6 +214,19 @@ int aur_envelope_vertices(aur_ctx* ctx, const float* d_logspec, const double* d_
                           int n_frames, const aur_envelope_params* params, const double* d_cos_sin360, int W, int H,
                           double* d_verts, void* stream);
 
+/* Feather rings (`feather_enabled`, rt_widget.py:1098-1117): six scaled copies k = 1..6 of
+ *   r = (inner + amp_noise sin(2 a_i + phase) + amp_audio spec_norm[si]) (1 + 0.015 k), 361 vertices each.
+ * d_rings: float64 [n_frames, 6, 361, 2].  Rasterise them with aur_mask_polygon (6 n_frames polygons) into planes
+ * [n_frames, 6, H, ceil(W/32)] and apply them with aur_feather_blend, which source-over blends
+ * QColor(13, 13, 18, max(10, 70 - 10 k)) into the finished RGB24 frames in ring order (Qt's premultiplied ARGB32
+ * arithmetic with div255(x) = (x + (x >> 8) + 0x80) >> 8; parity-unpinned against Qt's raster engine).
+ * n_frames <= 10922 per call. */
+int aur_feather_ring_vertices(aur_ctx* ctx, const float* d_logspec, const double* d_energy, const double* d_phase,
+                              int n_frames, const aur_envelope_params* params, const double* d_cos_sin360, int W, int H,
+                              double* d_rings, void* stream);
+int aur_feather_blend(aur_ctx* ctx, const uint32_t* d_ring_planes, int n_frames, int W, int H, uint8_t* d_frames,
+                      void* stream);
+
 /* "Waveform - Circular" (`_draw_waveform`, circular branch, rt_widget.py:871-896): the closed path through all
  * 1024 samples of a frame (segs = min(720, n), step = max(1, int(n / segs)) = 1),
  *   r = 0.28 min(W,H) + float(samples[i]) * 0.22 min(W,H) (0.5 + 0.6 energy),  (x, y) = (W/2 + cos(a_i) r, H/2 + sin(a_i) r).

@@ -321,7 +321,9 @@ def psnr(a: np.ndarray, b: np.ndarray) -> float:
 #   * the centre disc (rt_widget.py:1056-1096, QColor(30, 30, 40)) is an even-odd polygon fill sampled at pixel
 #     centres.  The reference fills it through an antialiased clip; antialiased edge blending is NOT reproduced
 #     (documented difference on the one-pixel rim of the disc; Qt coverage is parity-unpinned anyway);
-#   * feather rings (rt_widget.py:1098-1117, only with feather_enabled, which has no UI control) are not rendered.
+#   * feather rings (rt_widget.py:1098-1117, only with feather_enabled, which has no UI control): six aliased even-odd
+#     fills of QColor(13, 13, 18, alpha) blended source-over in ring order with Qt's premultiplied ARGB32 arithmetic,
+#     d' = div255(c a) + div255(d (255 - a)), div255(x) = (x + (x >> 8) + 0x80) >> 8 (parity-unpinned like the rest).
 # Masks are bit planes uint32[H, ceil(W / 32)], bit (x & 31) of word x >> 5.  All geometry is float64 with the
 # operation order below; the HIP kernels (csrc/radial.hip) use the same order with contraction disabled.
 
@@ -428,12 +430,27 @@ def unpack_mask(mask, w):
     return bits.reshape(mask.shape[0], -1)[:, :w]
 
 
-def render_radial_frame(path_verts, env_verts, pen_rgb, w, h, bg=BG):
-    """One "Spectrum - Radial" frame: background, radial stroke in the pen colour, centre disc on top."""
+def _div255(x):
+    return (x + (x >> 8) + 0x80) >> 8
+
+
+def blend_solid(frame, mask_bool, rgb, alpha):
+    """Source-over of the constant colour (rgb, alpha) on the pixels of ``mask_bool``, in place (Qt BYTE_MUL form)."""
+    d = frame[mask_bool].astype(np.uint32)
+    c = np.asarray(rgb, dtype=np.uint32)
+    a = np.uint32(alpha)
+    frame[mask_bool] = (_div255(c * a) + _div255(d * (np.uint32(255) - a))).astype(np.uint8)
+
+
+def render_radial_frame(path_verts, env_verts, pen_rgb, w, h, bg=BG, rings=None):
+    """One "Spectrum - Radial" frame: background, radial stroke in the pen colour, centre disc on top, then the
+    feather rings ``[(vertices, alpha)]`` (radial_ref.feather_ring_paths) blended in order."""
     frame = np.empty((h, w, 3), dtype=np.uint8)
     frame[:] = np.asarray(bg, dtype=np.uint8)
     frame[unpack_mask(stroke_mask_closed(path_verts, w, h), w)] = np.asarray(pen_rgb, dtype=np.uint8)
     frame[unpack_mask(polygon_mask(env_verts, w, h), w)] = np.asarray(DISC_RGB, dtype=np.uint8)
+    for verts, alpha in (rings or []):
+        blend_solid(frame, unpack_mask(polygon_mask(verts, w, h), w), bg, alpha)
     return frame
 
 

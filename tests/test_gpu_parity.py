@@ -381,7 +381,6 @@ def test_radial_vertices_vs_reference_paths(eng, fixture):
     audio, sr, fps = g["audio"], int(g["sample_rate"]), int(g["fps"])
     if fixture.startswith("radialvs"):
         vs, sens = json.loads(str(g["view_state_json"])), float(g["sensitivity"])
-        vs.pop("feather_enabled", None)                      # rings are not rendered; paths do not depend on it
         sizes = [tuple(int(v) for v in g["size"])]
         key = lambda wh, f: f"f{f}"
     else:
@@ -592,3 +591,56 @@ def test_pipeline_yuv420p_stream(eng):
         assert np.array_equal(raw[f], WR.rgb24_to_yuv420p(rgb[f])), f
     with pytest.raises(ValueError):
         FramePipeline(eng, track, "Spectrum - Linear", 322, H, wire_format="yuv420p")
+
+
+# ------------------------------------------------------------------ feather rings
+
+def test_feather_ring_vertices_vs_reference(eng):
+    """GPU feather ring paths vs the six fillPath polygons the reference produced (fixture radialvs_mirror_wavy:
+    mirror, waviness, audio-reactive term, rotation); device sin, so a few ulp, not bit-exact."""
+    import json
+    from aurora_amd import _lib
+    g = load_golden("radialvs_mirror_wavy")
+    audio, sr, fps = g["audio"], int(g["sample_rate"]), int(g["fps"])
+    vs, sens = json.loads(str(g["view_state_json"])), float(g["sensitivity"])
+    W, H = (int(v) for v in g["size"])
+    cfg = _radial_cfg(vs, sens)
+    assert cfg.feather_enabled
+    track = eng.upload_track(audio, sr, fps)
+    an = eng.analyze(track)
+    sc = eng.scan(an, _lib.ScanParams.defaults(sens))
+    prep = eng.radial_prepare(an, cfg)
+    rings = _np(eng.feather_ring_vertices(prep, an, sc, W, H, 0, an.n_frames))
+    worst, seen = 0.0, 0
+    for f in g["frames"]:
+        want = g[f"f{int(f)}_rings"]
+        assert rings[f].shape == want.shape == (6, 361, 2)
+        worst = max(worst, float(np.max(np.abs(rings[f] - want))))
+        seen += 1
+    print(f"feather rings: max |dx| {worst:.3e} px over {seen} frames")
+    assert seen > 0 and worst <= 2e-3       # inherits the spectrum's last-ulp float32 difference through spec_norm
+
+
+@pytest.mark.parametrize("size", [(640, 368), (1280, 720)])
+def test_feather_raster_bit_exact_given_same_vertices(eng, size):
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    W, H = size
+    sr, fps = 48000, 60
+    audio = synth.pink(5000, 2, seed=18)
+    track = eng.upload_track(audio, sr, fps)
+    cfg = _radial_cfg(dict(edge_waviness=70, feather_enabled=True, feather_audio_enabled=True, feather_audio_amount=50,
+                           radial_rotation_deg=5.0))
+    pipe = FramePipeline(eng, track, "Spectrum - Radial", W, H, radial=cfg)
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    prep = pipe._radial_prep
+    verts, env = eng.radial_vertices(prep, an, sc, W, H, 0, an.n_frames)
+    rings = _np(eng.feather_ring_vertices(prep, an, sc, W, H, 0, an.n_frames))
+    verts, env, pen = _np(verts), _np(env), _np(sc.pen_rgb)[:, :3]
+    alphas = [max(10, 70 - 10 * k) for k in range(1, 7)]
+    for f in range(an.n_frames):
+        want = R.render_radial_frame(verts[f], env[f], pen[f], W, H, rings=list(zip(rings[f], alphas)))
+        assert np.array_equal(frames[f], want), (size, f, int(np.sum(frames[f] != want)))
+    plain = R.render_radial_frame(verts[0], env[0], pen[0], W, H)
+    assert np.sum(frames[0] != plain) > 1000          # the rings changed the disc

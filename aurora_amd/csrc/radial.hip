@@ -677,27 +677,32 @@ extern "C" int aur_envelope_vertices(aur_ctx* ctx, const float* d_logspec, const
     return AUR_OK;
 }
 
-// ---- feather blend ------------------------------------------------------------------------------------------------
-// `p.fillPath(feather_path, col)` for k = 1..6 with col = QColor(13, 13, 18, max(10, 70 - 10 k)) (:1099-1117), no
-// antialiasing (the hint was restored off at :1096): source-over of a constant translucent colour wherever ring k
-// covers a pixel centre.  Arithmetic = Qt's premultiplied ARGB32 source-over,
+// ---- plane blend --------------------------------------------------------------------------------------------------
+// Source-over of K constant colours (r, g, b, a), plane k wherever its bit is set, in plane order, into finished RGB24
+// frames.  Used for the feather rings: `p.fillPath(feather_path, col)` for k = 1..6 with col = QColor(13, 13, 18,
+// max(10, 70 - 10 k)) (:1099-1117), no antialiasing (the hint was restored off at :1096); a = 255 overwrites (a disc
+// composited over a frame of another mode).  Arithmetic = Qt's premultiplied ARGB32 source-over,
 //   d' = div255(c a) + div255(d (255 - a)),   div255(x) = (x + (x >> 8) + 0x80) >> 8      (parity-unpinned vs Qt).
-// One thread per 32-pixel word of a row: reads the six ring words, returns when none is set (most of the frame).
-__device__ __forceinline__ uint32_t div255(uint32_t x) { return (x + (x >> 8) + 0x80u) >> 8; }
+// One thread per 32-pixel word of a row: reads the K plane words, returns when none is set (most of the frame).
+constexpr int kBlendMaxK = 8;
+struct BlendColours {
+    uint32_t pm[kBlendMaxK][3];      // premultiplied source div255(c a), per channel (computed on the host)
+    uint32_t inv[kBlendMaxK];        // 255 - a
+};
+__host__ __device__ __forceinline__ uint32_t div255(uint32_t x) { return (x + (x >> 8) + 0x80u) >> 8; }
 
-__global__ __launch_bounds__(256) void feather_blend_kernel(const uint32_t* __restrict__ ring_planes, int W, int H,
-                                                            int W32, uint8_t* __restrict__ frames) {
+__global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __restrict__ planes, int K, BlendColours col,
+                                                           int W, int H, int W32, uint8_t* __restrict__ frames) {
     const int f = blockIdx.z, row = blockIdx.y;
     const int w = blockIdx.x * 256 + threadIdx.x;
     if (w >= W32) return;
-    uint32_t m[6], any = 0;
+    uint32_t m[kBlendMaxK], any = 0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        m[k] = ring_planes[(((size_t)f * 6 + k) * H + row) * W32 + w];
+    for (int k = 0; k < kBlendMaxK; ++k) {
+        m[k] = (k < K) ? planes[(((size_t)f * K + k) * H + row) * W32 + w] : 0u;
         any |= m[k];
     }
     if (any == 0) return;
-    const uint32_t bg[3] = {13u, 13u, 18u};                                  // :1099
     uint8_t* px = frames + (((size_t)f * H + row) * W + (size_t)w * 32) * 3;
     while (any) {
         const int b = __builtin_ctz(any);
@@ -705,11 +710,10 @@ __global__ __launch_bounds__(256) void feather_blend_kernel(const uint32_t* __re
         if (w * 32 + b >= W) break;
         uint32_t c[3] = {px[3 * b], px[3 * b + 1], px[3 * b + 2]};
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < kBlendMaxK; ++k) {
             if ((m[k] >> b) & 1u) {
-                const uint32_t a = (uint32_t)max(10, 70 - 10 * (k + 1));     // :1116
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) c[ch] = div255(bg[ch] * a) + div255(c[ch] * (255u - a));
+                for (int ch = 0; ch < 3; ++ch) c[ch] = col.pm[k][ch] + div255(c[ch] * col.inv[k]);
             }
         }
         px[3 * b] = (uint8_t)c[0];
@@ -759,18 +763,25 @@ extern "C" int aur_feather_ring_vertices(aur_ctx* ctx, const float* d_logspec, c
     return AUR_OK;
 }
 
-extern "C" int aur_feather_blend(aur_ctx* ctx, const uint32_t* d_ring_planes, int n_frames, int W, int H,
-                                 uint8_t* d_frames, void* stream) {
+extern "C" int aur_blend_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t* h_rgba, int n_frames,
+                               int W, int H, uint8_t* d_frames, void* stream) {
     int rc = aur_use_device(ctx);
     if (rc) return rc;
-    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535 / 6, "aur_feather_blend: n_frames %d outside [0, %d]", n_frames,
-                65535 / 6);
-    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_feather_blend: frame size %dx%d unsupported", W, H);
+    AUR_REQUIRE(K >= 1 && K <= kBlendMaxK, "aur_blend_planes: K %d outside [1, %d]", K, kBlendMaxK);
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_blend_planes: n_frames %d outside [0, 65535]", n_frames);
+    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_blend_planes: frame size %dx%d unsupported", W, H);
+    AUR_REQUIRE(h_rgba != nullptr, "aur_blend_planes: null colour table");
     if (n_frames == 0) return AUR_OK;
-    AUR_REQUIRE(d_ring_planes && d_frames, "aur_feather_blend: null device pointer");
+    AUR_REQUIRE(d_planes && d_frames, "aur_blend_planes: null device pointer");
+    BlendColours col = {};
+    for (int k = 0; k < K; ++k) {
+        const uint32_t a = h_rgba[4 * k + 3];
+        for (int ch = 0; ch < 3; ++ch) col.pm[k][ch] = div255((uint32_t)h_rgba[4 * k + ch] * a);
+        col.inv[k] = 255u - a;
+    }
     const int W32 = (W + 31) / 32;
-    hipLaunchKernelGGL(feather_blend_kernel, dim3((W32 + 255) / 256, H, n_frames), dim3(256), 0, (hipStream_t)stream,
-                       d_ring_planes, W, H, W32, d_frames);
+    hipLaunchKernelGGL(blend_planes_kernel, dim3((W32 + 255) / 256, H, n_frames), dim3(256), 0, (hipStream_t)stream,
+                       d_planes, K, col, W, H, W32, d_frames);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

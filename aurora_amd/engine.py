@@ -419,18 +419,36 @@ class HipExportEngine:
             self.stream()), "aur_feather_ring_vertices")
         return rings
 
-    def feather_blend(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int, frames):
-        """Blends the six translucent rings of frames first .. first + count into ``frames`` (in place)."""
+    # QColor(13, 13, 18) with alpha max(10, 70 - 10 k), k = 1..6 (rt_widget.py:1099, :1116)
+    FEATHER_RGBA = bytes(v for k in range(1, 7) for v in (13, 13, 18, max(10, 70 - 10 * k)))
+    DISC_RGBA = bytes((30, 30, 40, 255))                                    # rt_widget.py:1092/1094
+
+    def blend_planes(self, planes, rgba: bytes, frames):
+        """Source-over of constant colours, plane k of ``planes`` int32 [n, K, H, W32] in plane order, in place."""
+        n, K, H, W32 = (int(v) for v in planes.shape)
+        W = int(frames.shape[2])
+        assert len(rgba) == 4 * K and frames.shape[0] == n and frames.shape[1] == H and (W + 31) // 32 == W32
+        _lib.check(self.lib.aur_blend_planes(self.ctx.handle, _ptr(planes), K, rgba, n, W, H, _ptr(frames),
+                                             self.stream()), "aur_blend_planes")
+        return frames
+
+    def feather_blend(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int, frames,
+                      with_disc: bool = False):
+        """Blends the six translucent rings of frames first .. first + count into ``frames`` (in place).  with_disc:
+        the centre disc (30, 30, 40) is composited first from its own plane (frames of a mode that has no disc)."""
         h, st = self.ctx.handle, self.stream()
         W32 = (W + 31) // 32
-        step = 65535 // 6
+        K = 7 if with_disc else 6
+        step = 65535 // K
         for off in range(0, count, step):
             n = min(step, count - off)
             rings = self.feather_ring_vertices(prep, an, sc, W, H, first + off, n)
-            planes = self.empty((n, 6, H, W32), self.torch.int32)
-            _lib.check(self.lib.aur_mask_polygon(h, _ptr(rings), 361, 6 * n, W, H, _ptr(planes), st), "aur_mask_polygon")
-            _lib.check(self.lib.aur_feather_blend(h, _ptr(planes), n, W, H, _ptr(frames[off:off + n]), st),
-                       "aur_feather_blend")
+            if with_disc:
+                env = self._envelope(prep, an, sc, W, H, first + off, n)
+                rings = self.torch.cat([env[:, None], rings], dim=1).contiguous()
+            planes = self.empty((n, K, H, W32), self.torch.int32)
+            _lib.check(self.lib.aur_mask_polygon(h, _ptr(rings), 361, K * n, W, H, _ptr(planes), st), "aur_mask_polygon")
+            self.blend_planes(planes, (self.DISC_RGBA if with_disc else b"") + self.FEATHER_RGBA, frames[off:off + n])
         return frames
 
     def _envelope(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int):

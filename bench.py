@@ -111,8 +111,14 @@ def main():
     audio = synth.pink_device(n_samples, 2, 1234 + rank, device)      # input resident in HBM before timing
     track = eng.make_track(audio, sr, fps)
     F = track.total_frames
-    kind = mode_kind(args.mode)
+    # BASELINE.json configs[3]: "particle mode + audio-reactive image feather".  The reference draws the centre disc and
+    # its feather only in "Spectrum - Radial" (rt_widget.py:841-849), so this is the union of the work:
+    # particle frames with the audio-reactive disc envelope and the six feather rings composited on top.
+    union = args.mode == "Particles + Feather"
+    kind = mode_kind("Particles" if union else args.mode)
     radial = RadialConfig() if kind == "spectrum_radial" else None
+    feather = RadialConfig(feather_enabled=True, feather_audio_enabled=True, feather_audio_amount=60,
+                           edge_waviness=40) if union else None
     circular = kind == "waveform_circular"
     planes_mode = radial is not None or circular
     K = {"spectrum_linear": _lib.K_SPECTRUM, "particles": _lib.K_PARTICLES, "waveform_linear": _lib.K_WAVEFORM,
@@ -136,7 +142,7 @@ def main():
             e1.record()
             ev_stft.append((e0, e1, F))
         sc = eng.scan(an)
-        prep = eng.radial_prepare(an, radial) if radial is not None else None
+        prep = eng.radial_prepare(an, radial or feather) if (radial or feather) is not None else None
         done, i = 0, 0
         while done < F:
             n = min(B, F - done)
@@ -158,6 +164,8 @@ def main():
             if ev_fill is not None:
                 e1.record()
                 ev_fill.append((e0, e1, n))
+            if feather is not None:
+                eng.feather_blend(prep, an, sc, W, H, done, n, dev_frames[s][:n], with_disc=True)
             done += n
             i += 1
 

@@ -217,15 +217,18 @@ int aur_envelope_vertices(aur_ctx* ctx, const float* d_logspec, const double* d_
 /* Feather rings (`feather_enabled`, rt_widget.py:1098-1117): six scaled copies k = 1..6 of
  *   r = (inner + amp_noise sin(2 a_i + phase) + amp_audio spec_norm[si]) (1 + 0.015 k), 361 vertices each.
  * d_rings: float64 [n_frames, 6, 361, 2].  Rasterise them with aur_mask_polygon (6 n_frames polygons) into planes
- * [n_frames, 6, H, ceil(W/32)] and apply them with aur_feather_blend, which source-over blends
- * QColor(13, 13, 18, max(10, 70 - 10 k)) into the finished RGB24 frames in ring order (Qt's premultiplied ARGB32
- * arithmetic with div255(x) = (x + (x >> 8) + 0x80) >> 8; parity-unpinned against Qt's raster engine).
- * n_frames <= 10922 per call. */
+ * [n_frames, 6, H, ceil(W/32)] and apply them with aur_blend_planes.
+ *
+ * aur_blend_planes: source-over of K <= 8 constant colours h_rgba[K][4] (host array, r g b a), plane k wherever its bit
+ * is set, in plane order, in place on finished RGB24 frames: `p.fillPath(feather_path, QColor(13, 13, 18,
+ * max(10, 70 - 10 k)))`, k = 1..6 (rt_widget.py:1099-1117).  Qt's premultiplied ARGB32 arithmetic,
+ *   d' = div255(c a) + div255(d (255 - a)), div255(x) = (x + (x >> 8) + 0x80) >> 8; a = 255 overwrites
+ * (parity-unpinned against Qt's raster engine).  d_planes: uint32 [n_frames, K, H, ceil(W/32)]. */
 int aur_feather_ring_vertices(aur_ctx* ctx, const float* d_logspec, const double* d_energy, const double* d_phase,
                               int n_frames, const aur_envelope_params* params, const double* d_cos_sin360, int W, int H,
                               double* d_rings, void* stream);
-int aur_feather_blend(aur_ctx* ctx, const uint32_t* d_ring_planes, int n_frames, int W, int H, uint8_t* d_frames,
-                      void* stream);
+int aur_blend_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t* h_rgba /*[K][4]*/, int n_frames,
+                     int W, int H, uint8_t* d_frames, void* stream);
 
 /* "Waveform - Circular" (`_draw_waveform`, circular branch, rt_widget.py:871-896): the closed path through all
  * 1024 samples of a frame (segs = min(720, n), step = max(1, int(n / segs)) = 1),

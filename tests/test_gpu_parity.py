@@ -644,3 +644,32 @@ def test_feather_raster_bit_exact_given_same_vertices(eng, size):
         assert np.array_equal(frames[f], want), (size, f, int(np.sum(frames[f] != want)))
     plain = R.render_radial_frame(verts[0], env[0], pen[0], W, H)
     assert np.sum(frames[0] != plain) > 1000          # the rings changed the disc
+
+
+def test_particles_with_feathered_disc_composite(eng):
+    """BASELINE configs[3] workload (particles + audio-reactive feather): the union composite bench.py times, checked
+    against the oracle's particle frame with the disc and the six rings blended on top."""
+    from aurora_amd import synth
+    from aurora_amd.engine import RadialConfig
+    from oracle import radial_ref as RR
+    W, H, sr, fps = 640, 360, 48000, 60
+    audio = synth.pink(4000, 2, seed=31)
+    track = eng.upload_track(audio, sr, fps)
+    an = eng.analyze(track)
+    sc = eng.scan(an)
+    cfg = RadialConfig(feather_enabled=True, feather_audio_enabled=True, feather_audio_amount=60, edge_waviness=40)
+    prep = eng.radial_prepare(an, cfg)
+    frames = eng.render("Particles", an, sc, W, H)
+    eng.feather_blend(prep, an, sc, W, H, 0, an.n_frames, frames, with_disc=True)
+    frames = _np(frames)
+    env = _np(eng._envelope(prep, an, sc, W, H, 0, an.n_frames))
+    rings = _np(eng.feather_ring_vertices(prep, an, sc, W, H, 0, an.n_frames))
+    ls, energy, pen = _np(an.logspec), _np(sc.energy), _np(sc.pen_rgb)[:, :3]
+    samples = np.zeros(1024, np.float32)
+    alphas = [max(10, 70 - 10 * k) for k in range(1, 7)]
+    for f in range(an.n_frames):
+        want = R.render_frame("Particles", samples, ls[f], float(energy[f]), pen[f], W, H)
+        want[R.unpack_mask(R.polygon_mask(env[f], W, H), W)] = np.asarray(R.DISC_RGB, np.uint8)
+        for verts, a in zip(rings[f], alphas):
+            R.blend_solid(want, R.unpack_mask(R.polygon_mask(verts, W, H), W), R.BG, a)
+        assert np.array_equal(frames[f], want), (f, int(np.sum(frames[f] != want)))

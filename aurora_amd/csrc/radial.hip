@@ -430,8 +430,10 @@ __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restr
                                                            int W32, uint32_t* __restrict__ planes) {
     __shared__ double s_x[kPolyMaxV], s_y[kPolyMaxV];
     __shared__ double s_lo[2], s_hi[2];
-    __shared__ double s_xs[128][kPolyCross + 1];  // sorted crossings of each row (+1: rows on different banks)
-    __shared__ int s_c[128][kPolyCross + 1];      // the same as clipped pixel-span edges
+    // sorted crossings of each row (+1: rows on different banks); once sorted they are converted in place to clipped
+    // pixel-span edges (int i overlays the first half of double i / 2, which has been read by then): 39 KB per block
+    // instead of 56, i.e. 4 blocks per CU instead of 2
+    __shared__ double s_xs[128][kPolyCross + 1];
     __shared__ int s_cnt[128];
     const int f = blockIdx.y;
     const double* V = verts + (long)f * nv * 2;
@@ -482,7 +484,11 @@ __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restr
             below0 = below1;
         }
         m &= ~1;
-        for (int i = 0; i < m; ++i) s_c[threadIdx.x][i] = span_edge(xs[i], W);
+        int* cs = reinterpret_cast<int*>(xs);
+        for (int i = 0; i < m; ++i) {
+            const int c = span_edge(xs[i], W);
+            cs[i] = c;
+        }
     }
     s_cnt[threadIdx.x] = m;
     __syncthreads();
@@ -495,7 +501,8 @@ __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restr
         for (int w = lane; w < W32; w += 64) {
             uint32_t bits = 0;
             for (int i = 0; i < cnt; i += 2) {            // pixel centre px + 0.5 in [x_i, x_i+1)
-                const int c0 = s_c[wbase + rr][i], c1 = s_c[wbase + rr][i + 1];
+                const int* cs = reinterpret_cast<const int*>(s_xs[wbase + rr]);
+                const int c0 = cs[i], c1 = cs[i + 1];
                 const int a = c0 > 32 * w ? c0 : 32 * w;
                 const int b = c1 < 32 * w + 32 ? c1 : 32 * w + 32;
                 if (b > a) bits |= (0xffffffffu >> (32 - (b - a))) << (a - 32 * w);
@@ -683,7 +690,7 @@ extern "C" int aur_envelope_vertices(aur_ctx* ctx, const float* d_logspec, const
 // max(10, 70 - 10 k)) (:1099-1117), no antialiasing (the hint was restored off at :1096); a = 255 overwrites (a disc
 // composited over a frame of another mode).  Arithmetic = Qt's premultiplied ARGB32 source-over,
 //   d' = div255(c a) + div255(d (255 - a)),   div255(x) = (x + (x >> 8) + 0x80) >> 8      (parity-unpinned vs Qt).
-// One thread per 32-pixel word of a row: reads the K plane words, returns when none is set (most of the frame).
+// One thread per 32-pixel word of a frame: reads the K plane words, returns when none is set (most of the frame).
 constexpr int kBlendMaxK = 8;
 struct BlendColours {
     uint32_t pm[kBlendMaxK][3];      // premultiplied source div255(c a), per channel (computed on the host)
@@ -693,9 +700,10 @@ __host__ __device__ __forceinline__ uint32_t div255(uint32_t x) { return (x + (x
 
 __global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __restrict__ planes, int K, BlendColours col,
                                                            int W, int H, int W32, uint8_t* __restrict__ frames) {
-    const int f = blockIdx.z, row = blockIdx.y;
-    const int w = blockIdx.x * 256 + threadIdx.x;
-    if (w >= W32) return;
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;         // word of the frame: row * W32 + w
+    if (idx >= H * W32) return;
+    const int row = idx / W32, w = idx - row * W32;
     uint32_t m[kBlendMaxK], any = 0;
 #pragma unroll
     for (int k = 0; k < kBlendMaxK; ++k) {
@@ -780,7 +788,7 @@ extern "C" int aur_blend_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, c
         col.inv[k] = 255u - a;
     }
     const int W32 = (W + 31) / 32;
-    hipLaunchKernelGGL(blend_planes_kernel, dim3((W32 + 255) / 256, H, n_frames), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(blend_planes_kernel, dim3((H * W32 + 255) / 256, n_frames), dim3(256), 0, (hipStream_t)stream,
                        d_planes, K, col, W, H, W32, d_frames);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;

@@ -14,8 +14,9 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("stft_frames_kernel", "raster_fill16_kernel", "raster_fill_kernel", "scan_frames_kernel",
-                "spans_spectrum_kernel", "spans_waveform_kernel", "spans_particles_kernel"):
+    for key in ("stft_frames_kernel", "raster_fill_lin_kernel", "raster_fill16_kernel", "raster_fill_kernel",
+                "span_summary_kernel", "scan_frames_kernel", "spans_spectrum_kernel", "spans_waveform_kernel",
+                "spans_particles_kernel"):
         if key in name:
             return key
     return None
@@ -47,7 +48,8 @@ def main(root):
     tj = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --steps 1 --warmup 0 "
                     "--cpu-frames 0 --pcie-frames 0` (tools/pmc_passes.sh); bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE",
           "raster_fill": {"config": os.environ.get("AUR_PMC_FILL_CONFIG", "3840x2160x128"),
-                          "hbm_bytes_per_launch": traffic("raster_fill16_kernel")},
+                          "kernel": "raster_fill_lin_kernel",
+                          "hbm_bytes_per_launch": traffic("raster_fill_lin_kernel")},
           "stft": {"frames": int(os.environ.get("AUR_PMC_STFT_FRAMES", "216000")),
                    "hbm_bytes_per_launch": traffic("stft_frames_kernel")}}
     with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:

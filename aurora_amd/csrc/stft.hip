@@ -44,7 +44,11 @@ namespace {
 #define AUR_STFT_WAVES_PER_WG 4
 #endif
 #ifndef AUR_STFT_MID_AT
-#define AUR_STFT_MID_AT 0              // unpack slot before which the next block's loads are issued (0: before the unpack)
+#define AUR_STFT_MID_AT 4              // unpack slot before which the next block's loads are issued: half of v[] is dead there,
+                                       // so the 32 load registers cost no extra pressure (0: before the unpack)
+#endif
+#ifndef AUR_STFT_WAVES_PER_CU
+#define AUR_STFT_WAVES_PER_CU (4 * AUR_STFT_WAVES_PER_SIMD)   // resident waves per CU (limited by LDS when it is not this)
 #endif
 constexpr int kWavesPerWG = AUR_STFT_WAVES_PER_WG;
 constexpr int kXbufDoubles = 16 * 66;            // exchange buffer per wave: 16 rows of 66 doubles, 8448 B
@@ -53,7 +57,11 @@ constexpr int kTw2Stride = 17;                   // complex doubles per W64 row 
 constexpr int kLdsTw2Bytes = 4 * kTw2Stride * 16;   // W64^(r q), complex double
 constexpr int kLdsTw1Bytes = 15 * 64 * 16;          // W1024^(l k1), complex double [k1 - 1][l]
 constexpr int kLdsTabBytes = kLdsWinBytes + kLdsTw2Bytes + kLdsTw1Bytes;
-constexpr int kLdsBytes = kLdsTabBytes + kWavesPerWG * kXbufDoubles * 8;
+#ifndef AUR_STFT_PMAG_LDS
+#define AUR_STFT_PMAG_LDS 0
+#endif
+constexpr int kPmagBytes = AUR_STFT_PMAG_LDS ? 17 * 64 * 4 : 0;      // per wave
+constexpr int kLdsBytes = kLdsTabBytes + kWavesPerWG * (kXbufDoubles * 8 + kPmagBytes);
 
 struct cd {
     double x, y;
@@ -380,12 +388,36 @@ __device__ __forceinline__ int slot_bin(int lane, int p) {
     return lane + 64 * (ql + 4 * s) + ((lane == 0 && ql == 0 && s >= 2) ? 128 : 0);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));     // (bin kA, bin 1024 - kA) of a slot: packed float32 math
+
 struct Mags {
-    float a[8], b[8], mid;
-    __device__ __forceinline__ float swap_a(int p, float m) { const float t = a[p]; a[p] = m; return t; }
-    __device__ __forceinline__ float swap_b(int p, float m) { const float t = b[p]; b[p] = m; return t; }
+    v2f ab[8];
+    float mid;
+    __device__ __forceinline__ v2f swap(int p, v2f m) { const v2f t = ab[p]; ab[p] = m; return t; }
     __device__ __forceinline__ float swap_mid(float m) { const float t = mid; mid = m; return t; }
 };
+
+// The same state parked in LDS (float [17][64] per wave, lane-private columns: no conflicts, no synchronisation):
+// 17 registers fewer across the whole frame for 34 LDS accesses per frame.  Build knob AUR_STFT_PMAG_LDS.
+struct MagsLds {
+    float* col;          // &area[lane]
+    __device__ __forceinline__ v2f swap(int p, v2f m) {
+        const v2f t = {col[64 * (2 * p)], col[64 * (2 * p + 1)]};
+        col[64 * (2 * p)] = m.x;
+        col[64 * (2 * p + 1)] = m.y;
+        return t;
+    }
+    __device__ __forceinline__ float swap_mid(float m) { const float t = col[64 * 16]; col[64 * 16] = m; return t; }
+};
+
+// log1p_pos on both bins of a slot (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32; the logarithms stay scalar)
+__device__ __forceinline__ v2f log1p_pos2(v2f x) {
+    const v2f u = 1.0f + x;
+    const v2f c = x - (u - 1.0f);
+    const v2f t = __builtin_elementwise_max(2.0f - u, (v2f)(0.0f));
+    const v2f lg = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
+    return __builtin_elementwise_fma(c, t, lg * 0.693147180559945309f);
+}
 
 // Real-FFT unpack -> |X| -> flux partial vs pm (updated in place) -> log1p.
 // X[kA] = E + T and X[kB] = conj(E - T), kB = 1024 - kA, share E = (Z[kA] + conj Z[kB]) / 2 and
@@ -416,7 +448,7 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
     th[5] = cmul(wuh, cd{kW32re5, kW32im5});                           // j = 5
     th[6] = mul_mi(th[4]);                                             // j = 9
     th[7] = mul_mi(th[5]);                                             // j = 13
-    float fl = 0.0f;
+    v2f fl2 = {0.0f, 0.0f};
     // per-frame store addresses; the 64 j steps are instruction offsets
     float* const out_a = out + lane;
     float* const out_b = out + (1024 - lane);
@@ -438,25 +470,24 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
         const double ty = fma(th[p].x, oy, th[p].y * ox);
         const double ar = fma(0.5, ex, tx), ai = fma(0.5, ey, ty);
         const double br = fma(0.5, ex, -tx), bi = fma(0.5, ey, -ty);
-        const float ma = mag_from_sq(fma(ar, ar, ai * ai));
-        const float mb = mag_from_sq(fma(br, br, bi * bi));
-        fl += fmaxf(0.0f, ma - pm.swap_a(p, ma));
-        fl += fmaxf(0.0f, mb - pm.swap_b(p, mb));
+        const v2f m = {mag_from_sq(fma(ar, ar, ai * ai)), mag_from_sq(fma(br, br, bi * bi))};
+        fl2 += __builtin_elementwise_max(m - pm.swap(p, m), (v2f)(0.0f));
         if (EMIT) {
-            const float la = log1p_pos(ma), lb = log1p_pos(mb);
-            if (j == 0) lg0 = la;
-            if (j == 1) lg1 = la;
+            const v2f l = log1p_pos2(m);
+            if (j == 0) lg0 = l.x;
+            if (j == 1) lg1 = l.x;
             if (STORE_LOG) {
                 if (p == 2 || p == 3) {
-                    out_a2[64 * j] = la;          // bin off2 + 64 j
-                    out_b2[-64 * j] = lb;
+                    out_a2[64 * j] = l.x;         // bin off2 + 64 j
+                    out_b2[-64 * j] = l.y;
                 } else {
-                    out_a[64 * j] = la;           // bin lane + 64 j
-                    out_b[-64 * j] = lb;          // bin 1024 - lane - 64 j
+                    out_a[64 * j] = l.x;          // bin lane + 64 j
+                    out_b[-64 * j] = l.y;         // bin 1024 - lane - 64 j
                 }
             }
         }
     }
+    float fl = fl2.x + fl2.y;
     {   // bin 512 (lane 0): X[512] = conj(Z[512])
         const cd z8 = v[2];
         const float mm = mag_from_sq(fma(z8.x, z8.x, z8.y * z8.y));
@@ -470,7 +501,7 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
 
 __device__ __forceinline__ void mags_zero(Mags& m) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) m.a[p] = m.b[p] = 0.0f;
+    for (int p = 0; p < 8; ++p) m.ab[p] = v2f{0.0f, 0.0f};
     m.mid = 0.0f;
 }
 
@@ -478,8 +509,7 @@ __device__ __forceinline__ void mags_load(Mags& m, const float* __restrict__ src
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int k = slot_bin(lane, p);
-        m.a[p] = src[k];
-        m.b[p] = src[1024 - k];
+        m.ab[p] = v2f{src[k], src[1024 - k]};
     }
     m.mid = src[512];
 }
@@ -488,8 +518,8 @@ __device__ __forceinline__ void mags_store(const Mags& m, float* __restrict__ ds
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int k = slot_bin(lane, p);
-        dst[k] = m.a[p];
-        dst[1024 - k] = m.b[p];
+        dst[k] = m.ab[p].x;
+        dst[1024 - k] = m.ab[p].y;
     }
     if (lane == 0) dst[512] = m.mid;
 }
@@ -517,9 +547,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     if (c0 >= frame_end) return;   // no block-level barrier below this point
     const long cend = (c0 + frames_per_wave < frame_end) ? c0 + frames_per_wave : frame_end;
 
+#if AUR_STFT_PMAG_LDS
+    MagsLds pmag;                         // Analyzer.prev_mag of this wave's bins, lane-private LDS columns
+    pmag.col = reinterpret_cast<float*>(smem + kLdsTabBytes + kWavesPerWG * kXbufDoubles * 8) + wave * 17 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) pmag.col[64 * i] = 0.0f;
+#else
     Mags pmag;                            // Analyzer.prev_mag of this wave's bins
-    cd v[16];
     mags_zero(pmag);
+#endif
+    cd v[16];
 
     // Analyzer.buffer starts at zero (analysis.py:14); a chunk that starts inside the track first replays frame
     // c0 - 1 (the halo) to rebuild Analyzer.prev_mag, storing nothing.
@@ -621,7 +658,7 @@ int launch_stft(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int
                 float* d_bandmax, hipStream_t st) {
     // frames per wave: the range is cut into k rounds of one wave per wave slot (2 per SIMD), k as small as keeps a
     // wave at <= 64 frames: long chunks amortise the 1-frame halo, whole rounds leave no tail (216 000 frames: 53)
-    const long slots = (long)ctx->num_cus * 4 * AUR_STFT_WAVES_PER_SIMD;
+    const long slots = (long)ctx->num_cus * AUR_STFT_WAVES_PER_CU;
     const long rounds = (n_frames + slots * 64 - 1) / (slots * 64);
     int fpw = (int)((n_frames + slots * rounds - 1) / (slots * rounds));
     if (fpw < 4) fpw = 4;

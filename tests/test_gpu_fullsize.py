@@ -92,7 +92,8 @@ def test_full_track_sampled_frames_vs_oracle(eng, track4min):
 
 
 @pytest.mark.parametrize("mode,size", [("Spectrum - Linear", (1920, 1080)), ("Waveform - Linear", (3840, 2160)),
-                                       ("Particles", (1920, 1080)), ("Spectrum - Radial", (1920, 1080))])
+                                       ("Particles", (1920, 1080)), ("Spectrum - Radial", (1920, 1080)),
+                                       ("Waveform - Circular", (1920, 1080))])
 def test_full_track_render_checksums_and_samples(eng, track4min, mode, size):
     """Whole 4-minute render in batches: (a) batch size does not change a byte (checksum of checksums),
     (b) sampled frames equal the oracle rasteriser fed the GPU's analysis values, (c) every pixel is one of the
@@ -103,11 +104,14 @@ def test_full_track_render_checksums_and_samples(eng, track4min, mode, size):
     W, H = size
     F = track.total_frames
     radial = mode_kind(mode) == "spectrum_radial"
+    circular = mode_kind(mode) == "waveform_circular"
     prep = eng.radial_prepare(an, RadialConfig()) if radial else None
 
     def render(first, count):
         if radial:
             return eng.render_radial(prep, an, sc, W, H, first, count)
+        if circular:
+            return eng.render_wave_circular(an, sc, W, H, first, count)
         return eng.render(mode, an, sc, W, H, first, count)
 
     def digest(batch):
@@ -136,6 +140,10 @@ def test_full_track_render_checksums_and_samples(eng, track4min, mode, size):
             verts, env = eng.radial_vertices(prep, an, sc, W, H, f, 1)
             want = R.render_radial_frame(_np(verts)[0], _np(env)[0], pen[f], W, H)
             palette = {tuple(R.BG), tuple(pen[f]), tuple(R.DISC_RGB)}
+        elif circular:
+            from oracle import radial_ref as RR
+            want = R.render_wave_circular_frame(RR.wave_circular_path(_np(smp[f]), float(energy[f]), W, H), pen[f], W, H)
+            palette = {tuple(R.BG), tuple(pen[f])}
         else:
             want = R.render_frame(mode, _np(smp[f]), _np(ls[f]), float(energy[f]), pen[f], W, H)
             palette = {tuple(R.BG), tuple(pen[f])}

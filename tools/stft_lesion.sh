@@ -28,6 +28,10 @@ if [ "$1" = build ]; then
       w3)    extra="-DAUR_STFT_WAVES_PER_SIMD=3 -DAUR_STFT_WAVES_PER_WG=12 -DAUR_STFT_MID_AT=4" ;;
       w3b)   extra="-DAUR_STFT_WAVES_PER_SIMD=3 -DAUR_STFT_WAVES_PER_WG=6 -DAUR_STFT_MID_AT=4" ;;
       mid4)  extra="-DAUR_STFT_MID_AT=4" ;;
+      w10l)  extra="-DAUR_STFT_WAVES_PER_SIMD=3 -DAUR_STFT_WAVES_PER_WG=10 -DAUR_STFT_WAVES_PER_CU=10 -DAUR_STFT_MID_AT=4 -DAUR_STFT_PMAG_LDS=1" ;;
+      w5l)   extra="-DAUR_STFT_WAVES_PER_SIMD=3 -DAUR_STFT_WAVES_PER_WG=5 -DAUR_STFT_WAVES_PER_CU=10 -DAUR_STFT_MID_AT=4 -DAUR_STFT_PMAG_LDS=1" ;;
+      w8l)   extra="-DAUR_STFT_WAVES_PER_WG=8 -DAUR_STFT_MID_AT=4 -DAUR_STFT_PMAG_LDS=1" ;;
+      w8)    extra="-DAUR_STFT_WAVES_PER_WG=8" ;;
       mid6)  extra="-DAUR_STFT_MID_AT=6" ;;
     esac
     make -s -C $d/aurora_amd/csrc OUT=../../lib_$v.so BUILD=build EXTRA="$extra" > /dev/null

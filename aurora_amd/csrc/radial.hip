@@ -415,8 +415,8 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
     }
 }
 
-// Even-odd fill of the implicitly closed polygon verts[f][nv][2].  A thread finds the sorted crossings of one pixel
-// row (vertices staged in LDS; rows outside the polygon's y range have none) and leaves them as pixel spans in LDS;
+// Even-odd fill of the implicitly closed polygon verts[f][nv][2].  The edges (vertices staged in LDS) append their
+// crossings to the lists of the few pixel rows they span, a thread per row sorts its list into pixel spans in LDS;
 // then each wave writes its 64 rows word by word, one coalesced row at a time.  Every word of the plane is written,
 // so the plane needs no clearing.
 constexpr int kPolyMaxV = 384;                // the envelope has 361 vertices
@@ -429,59 +429,57 @@ __device__ __forceinline__ int span_edge(double x, int W) {
 __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restrict__ verts, int nv, int W, int H,
                                                            int W32, uint32_t* __restrict__ planes) {
     __shared__ double s_x[kPolyMaxV], s_y[kPolyMaxV];
-    __shared__ double s_lo[2], s_hi[2];
     // sorted crossings of each row (+1: rows on different banks); once sorted they are converted in place to clipped
     // pixel-span edges (int i overlays the first half of double i / 2, which has been read by then): 39 KB per block
-    // instead of 56, i.e. 4 blocks per CU instead of 2
     __shared__ double s_xs[128][kPolyCross + 1];
     __shared__ int s_cnt[128];
     const int f = blockIdx.y;
     const double* V = verts + (long)f * nv * 2;
-    double lo = kBig, hi = -kBig;
     for (int e = threadIdx.x; e < nv; e += 128) {
-        const double x = V[2 * e], y = V[2 * e + 1];
-        s_x[e] = x;
-        s_y[e] = y;
-        lo = fmin(lo, y);
-        hi = fmax(hi, y);
+        s_x[e] = V[2 * e];
+        s_y[e] = V[2 * e + 1];
     }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        lo = fmin(lo, __shfl_xor(lo, m, 64));
-        hi = fmax(hi, __shfl_xor(hi, m, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_lo[threadIdx.x >> 6] = lo;
-        s_hi[threadIdx.x >> 6] = hi;
+    // Edge-parallel crossing search: an edge crosses the sample line of row r (y = r + 0.5) iff exactly one of its end
+    // points is <= it, i.e. for the rows between ceil(ymin - 0.5) and ceil(ymax - 0.5) - 1; a thread walks the few rows
+    // of its edges (one candidate row more on either side, every row decided by the exact predicate, so rounding of
+    // the bounds cannot change the result) and appends the crossing to the row's list.  Rows are sorted afterwards, so
+    // the append order does not matter (lists longer than kPolyCross keep an unspecified subset; envelopes have 2-6).
+    const int base = blockIdx.x * 128;
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nv; e += 128) {
+        const int ep = (e == 0) ? nv - 1 : e - 1;
+        const double x0 = s_x[ep], y0 = s_y[ep], x1 = s_x[e], y1 = s_y[e];
+        double ya = fmin(y0, y1), yb = fmax(y0, y1);
+        if (!(ya == ya) || !(yb == yb)) continue;                    // NaN vertex: no crossing (comparisons are false)
+        ya = fmin(fmax(ya, -kBig), kBig);
+        yb = fmin(fmax(yb, -kBig), kBig);
+        long ra = (long)ceil(ya - 0.5) - 1, rb = (long)ceil(yb - 0.5);
+        if (ra < base) ra = base;
+        if (rb > base + 127) rb = base + 127;
+        if (rb > H - 1) rb = H - 1;
+        for (long r = ra; r <= rb; ++r) {
+            const double yc = (double)r + 0.5;
+            if ((y0 <= yc) != (y1 <= yc)) {
+                const double x = x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0);
+                const int slot = atomicAdd(&s_cnt[r - base], 1);
+                if (slot < kPolyCross) s_xs[r - base][slot] = x;
+            }
+        }
     }
     __syncthreads();
-    lo = fmin(s_lo[0], s_lo[1]);
-    hi = fmax(s_hi[0], s_hi[1]);
-    const int r = blockIdx.x * 128 + threadIdx.x;
-    const double yc = (double)r + 0.5;
-    int m = 0;
-    if (r < H && yc >= lo && yc <= hi) {
+    int m = s_cnt[threadIdx.x];
+    if (m > kPolyCross) m = kPolyCross;
+    {
         double* xs = s_xs[threadIdx.x];
-        double x0 = s_x[nv - 1], y0 = s_y[nv - 1];    // closing edge first: crossings are sorted anyway
-        bool below0 = y0 <= yc;
-#pragma unroll 4
-        for (int e = 0; e < nv; ++e) {
-            const double x1 = s_x[e], y1 = s_y[e];
-            const bool below1 = y1 <= yc;
-            if (below0 != below1) {
-                const double x = x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0);
-                if (m < kPolyCross) {
-                    int k = m++;
-                    while (k > 0 && xs[k - 1] > x) {      // insertion sort
-                        xs[k] = xs[k - 1];
-                        --k;
-                    }
-                    xs[k] = x;
-                }
+        for (int i = 1; i < m; ++i) {                                 // insertion sort of the row's crossings
+            const double x = xs[i];
+            int k = i;
+            while (k > 0 && xs[k - 1] > x) {
+                xs[k] = xs[k - 1];
+                --k;
             }
-            x0 = x1;
-            y0 = y1;
-            below0 = below1;
+            xs[k] = x;
         }
         m &= ~1;
         int* cs = reinterpret_cast<int*>(xs);

@@ -416,7 +416,7 @@ def polygon_mask(verts, w, h):
             x1, y1 = V[(e + 1) % n]
             if (y0 <= yc) != (y1 <= yc):
                 xs.append(x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0))
-        xs.sort()       # the kernel keeps the first 32 crossings of a row in edge order; envelopes stay far below that
+        xs.sort()       # the kernel keeps at most 32 crossings per row; envelopes stay far below that
         assert len(xs) <= 32
         for i in range(0, len(xs) - 1, 2):
             a = min(max(xs[i], -_BIG), _BIG)

@@ -219,3 +219,58 @@ def test_closed_stroke_and_polygon_masks_equal_brute_force(seed):
             xint = x0 + (cy - y0) * (x1 - x0) / (y1 - y0)
         inside ^= cond & (xint <= cx)
     assert np.array_equal(poly, inside)
+
+
+# ------------------------------------------------------------------ round-1 additions: circular waveform, wire, blend
+
+def test_wave_circular_angle_table_matches_oracle_expression():
+    from oracle import radial_ref as RR
+    for rot in (0.0, 33.0, -120.5):
+        cs = engine.wave_circular_angle_table(rot)
+        assert cs.shape == (1024, 2) and cs.dtype == np.float64
+        samples = np.zeros(1024, np.float32)
+        # r is constant for zero samples, so the oracle's path is (cx + cos a_i r, cy + sin a_i r)
+        path = RR.wave_circular_path(samples, 0.25, 1000, 562, rot)
+        r = min(1000, 562) * 0.28
+        assert np.array_equal(path[:, 0], 1000 / 2.0 + cs[:, 0] * r)
+        assert np.array_equal(path[:, 1], 562 / 2.0 + cs[:, 1] * r)
+
+
+def test_yuv420p_oracle_known_answers():
+    from oracle import wire_ref as WR
+    def solid(rgb):
+        f = np.empty((4, 8, 3), np.uint8)
+        f[:] = rgb
+        out = WR.rgb24_to_yuv420p(f)
+        assert out.shape == (4 * 8 * 3 // 2,)
+        return int(out[0]), int(out[32]), int(out[40])
+    assert solid((0, 0, 0)) == (16, 128, 128)            # BT.601 limited range black
+    assert solid((255, 255, 255)) == (235, 128, 128)     # white
+    assert solid((255, 0, 0)) == (82, 90, 240)           # the classic 8-bit integer red
+    assert solid((0, 0, 255)) == (41, 240, 110)
+    y, cb, cr = solid((13, 13, 18))                      # Aurora's background colour (rt_widget.py:829)
+    assert (y, cb, cr) == (28, 130, 128)              # (66*13 + 129*13 + 25*18 + 128 >> 8) + 16 = 12 + 16
+
+
+def test_blend_rule_is_qt_premultiplied_source_over():
+    # alpha 255 overwrites, alpha 0 keeps, and the six feather alphas over the disc colour give the documented value
+    f = np.zeros((2, 2, 3), np.uint8)
+    f[:] = (200, 100, 50)
+    m = np.ones((2, 2), bool)
+    R.blend_solid(f, m, (30, 30, 40), 255)
+    assert (f == (30, 30, 40)).all()
+    R.blend_solid(f, m, (13, 13, 18), 0)
+    assert (f == (30, 30, 40)).all()
+    for k in range(1, 7):
+        R.blend_solid(f, m, R.BG, max(10, 70 - 10 * k))
+    assert (f == (20, 20, 27)).all()
+
+
+def test_new_entry_points_reject_bad_arguments_without_gpu():
+    lib = _lib.load()
+    # every call fails on the null context before touching a device
+    assert lib.aur_rgb24_to_yuv420p(None, None, 1, 64, 64, None, None) != 0
+    assert lib.aur_blend_planes(None, None, 6, b"\0" * 24, 1, 64, 64, None, None) != 0
+    assert lib.aur_wave_circular_vertices(None, None, None, 1, None, 64, 64, None, None) != 0
+    assert lib.aur_feather_ring_vertices(None, None, None, None, 1, None, None, 64, 64, None, None) != 0
+    assert b"null" in lib.aur_last_error()

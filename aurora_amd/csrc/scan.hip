@@ -141,7 +141,8 @@ extern "C" int aur_scan_frames(aur_ctx* ctx, const float* d_meanabs, const float
     if (rc) return rc;
     AUR_REQUIRE(params != nullptr, "aur_scan_frames: null params");
     AUR_REQUIRE(n_frames >= 0, "aur_scan_frames: n_frames %d < 0", n_frames);
-    AUR_REQUIRE(d_meanabs && d_flux_sum, "aur_scan_frames: null input pointer");
+    AUR_REQUIRE(n_frames == 0 || (d_meanabs && d_flux_sum), "aur_scan_frames: null input pointer");   // 0 frames: the
+    // kernel still copies the carried state to d_state_out
     AUR_REQUIRE(params->grad_curve >= 0 && params->grad_curve <= 3, "aur_scan_frames: grad_curve %d unknown",
                 params->grad_curve);
     AUR_REQUIRE(params->amp_alpha >= 0.0 && params->amp_alpha <= 1.0, "aur_scan_frames: amp_alpha out of [0,1]");

@@ -208,6 +208,8 @@ class HipExportEngine:
         if ch not in (1, 2):
             raise _lib.AuroraHipError(f"{ch}-channel audio unsupported (mono or stereo)")
         hop, total, pos = frame_plan(n, sample_rate, fps)
+        if n < 2:       # the kernel loads sample pairs: a 0- or 1-sample file gets zero rows, which is what the
+            audio_dev = torch.cat([audio_dev, audio_dev.new_zeros((2 - n, ch))], dim=0)   # reference's padding reads
         pos_dev = torch.from_numpy(pos).to(self.device)
         return Track(audio_dev, pos_dev, pos, n, ch, int(sample_rate), int(fps), hop, total)
 
@@ -231,7 +233,7 @@ class HipExportEngine:
         samples = self.empty((F, BLOCK), torch.float32) if want_samples else None
         bandmax = self.empty((F, 2), torch.float32) if want_bandmax else None
         _lib.check(self.lib.aur_stft_frames(
-            self.ctx.handle, _ptr(track.audio), track.n_samples, track.channels, _ptr(track.pos),
+            self.ctx.handle, _ptr(track.audio), max(2, track.n_samples), track.channels, _ptr(track.pos),
             int(frame_begin), F, track.hop, _ptr(logspec), _ptr(flux_sum), _ptr(meanabs), _ptr(samples),
             _ptr(bandmax), self.stream()), "aur_stft_frames")
         return Analysis(int(frame_begin), F, logspec, flux_sum, meanabs, samples, bandmax)

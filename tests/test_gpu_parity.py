@@ -673,3 +673,20 @@ def test_particles_with_feathered_disc_composite(eng):
         for verts, a in zip(rings[f], alphas):
             R.blend_solid(want, R.unpack_mask(R.polygon_mask(verts, W, H), W), R.BG, a)
         assert np.array_equal(frames[f], want), (f, int(np.sum(frames[f] != want)))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 799, 801])
+def test_degenerate_track_lengths(eng, n):
+    """Empty, one-sample and sub-hop files: same frames, samples, energy and spectrum as the oracle."""
+    rng = np.random.default_rng(n)
+    audio = (rng.random((n, 2), dtype=np.float32) - 0.5)
+    ref = A.analyze_track(audio, 48000, 60)
+    track = eng.upload_track(audio, 48000, 60)
+    assert track.total_frames == ref["samples"].shape[0]
+    an = eng.analyze(track, want_samples=True)
+    sc = eng.scan(an)
+    assert an.n_frames == track.total_frames
+    if an.n_frames:
+        assert np.array_equal(_np(an.samples), ref["samples"])
+        assert np.array_equal(_np(sc.energy), ref["energy"])
+        assert np.allclose(_np(an.logspec), ref["logspec"], rtol=1e-4, atol=2e-6)

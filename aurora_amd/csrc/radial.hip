@@ -601,6 +601,25 @@ __global__ __launch_bounds__(256) void raster_fill_planes_kernel(const uint32_t*
     }
 }
 
+// Any width (W not a multiple of 16, or an unaligned batch): one thread per pixel, three byte stores.  Same colours
+// and painting order as raster_fill_planes_kernel; only odd export sizes such as 1366x768 come here.
+__global__ __launch_bounds__(256) void raster_fill_planes_px_kernel(const uint32_t* __restrict__ stroke,
+                                                                    const uint32_t* __restrict__ disc,
+                                                                    const uint32_t* __restrict__ pen_rgb, int W, int H,
+                                                                    int W32, int disc_static,
+                                                                    uint8_t* __restrict__ frames) {
+    const int f = blockIdx.z, row = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const uint32_t sb = (stroke[((long)f * H + row) * W32 + (x >> 5)] >> (x & 31)) & 1u;
+    const uint32_t db = (disc[((long)(disc_static ? 0 : f) * H + row) * W32 + (x >> 5)] >> (x & 31)) & 1u;
+    const uint32_t c = db ? kDisc24 : (sb ? (pen_rgb[f] & 0x00ffffffu) : kBg24);
+    uint8_t* px = frames + (((size_t)f * H + row) * W + x) * 3;
+    px[0] = (uint8_t)c;
+    px[1] = (uint8_t)(c >> 8);
+    px[2] = (uint8_t)(c >> 16);
+}
+
 }  // namespace
 
 extern "C" int aur_radial_stage1(aur_ctx* ctx, const float* d_logspec, int n_frames, int mirror, int wave_smoothness,
@@ -883,12 +902,17 @@ extern "C" int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, c
     if (rc) return rc;
     AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_raster_planes: n_frames %d outside [0, 65535]", n_frames);
     AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_raster_planes: frame size %dx%d unsupported", W, H);
-    AUR_REQUIRE(W % 16 == 0, "aur_raster_planes: width %d must be a multiple of 16", W);
     if (n_frames == 0) return AUR_OK;
     AUR_REQUIRE(d_stroke_plane && d_disc_plane && d_pen_rgb && d_frames, "aur_raster_planes: null device pointer");
-    AUR_REQUIRE(((uintptr_t)d_frames & 15u) == 0 && ((uintptr_t)d_pen_rgb & 3u) == 0,
-                "aur_raster_planes: misaligned device pointer");
+    AUR_REQUIRE(((uintptr_t)d_pen_rgb & 3u) == 0, "aur_raster_planes: misaligned d_pen_rgb");
     const int W32 = (W + 31) / 32;
+    if (W % 16 != 0 || ((uintptr_t)d_frames & 15u) != 0) {
+        hipLaunchKernelGGL(raster_fill_planes_px_kernel, dim3((W + 255) / 256, H, n_frames), dim3(256), 0,
+                           (hipStream_t)stream, d_stroke_plane, d_disc_plane,
+                           reinterpret_cast<const uint32_t*>(d_pen_rgb), W, H, W32, disc_static ? 1 : 0, d_frames);
+        AUR_CHECK_HIP(hipGetLastError());
+        return AUR_OK;
+    }
     const int nu4 = W * 3 / 16, nchunks = (nu4 + 63) / 64;
     const int ntiles = (H + kRowsPerTask - 1) / kRowsPerTask;
     hipLaunchKernelGGL(raster_fill_planes_kernel, dim3((nchunks * ntiles + 3) / 4, n_frames), dim3(256), 0,

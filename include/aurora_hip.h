@@ -252,7 +252,7 @@ int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_
 
 /* RGB24 frames of "Spectrum - Radial" / "Waveform - Circular" (paint_frame, rt_widget.py:821-852): background
  * (13,13,18), stroke plane in the pen colour, disc plane in (30,30,40) on top (an all-zero static plane when the mode
- * has no disc).  W must be a multiple of 16.  disc_static != 0: d_disc_plane holds ONE
+ * has no disc).  Widths that are not a multiple of 16 take a per-pixel kernel.  disc_static != 0: d_disc_plane holds ONE
  * plane [H, ceil(W/32)] used for every frame (the envelope does not depend on the frame when edge_waviness and the
  * audio term are off, which is the export default). */
 int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, const uint32_t* d_disc_plane, int disc_static,

@@ -448,7 +448,7 @@ def test_radial_chain_bit_exact_given_same_spectrum(eng):
         assert np.allclose(_np(env)[f], want_e, rtol=0, atol=1e-9), f
 
 
-@pytest.mark.parametrize("size", [(640, 368), (1280, 720)])
+@pytest.mark.parametrize("size", [(640, 368), (1280, 720), (1366, 768), (1000, 562)])
 def test_radial_raster_bit_exact_given_same_vertices(eng, size):
     from aurora_amd import synth
     from aurora_amd.pipeline import FramePipeline
@@ -512,7 +512,7 @@ def test_wave_circular_vertices_vs_reference_paths(eng, fixture):
     assert seen > 0
 
 
-@pytest.mark.parametrize("size", [(640, 368), (1280, 720)])
+@pytest.mark.parametrize("size", [(640, 368), (1280, 720), (1366, 768)])
 def test_wave_circular_raster_bit_exact(eng, size):
     from aurora_amd import synth
     from aurora_amd.pipeline import FramePipeline

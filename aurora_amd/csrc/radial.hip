@@ -415,62 +415,59 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
     }
 }
 
-// Even-odd fill of the implicitly closed polygon verts[f][nv][2].  The edges (vertices staged in LDS) append their
+// Even-odd fill of the implicitly closed polygon verts[f][nv][2].  The edges append their
 // crossings to the lists of the few pixel rows they span, a thread per row sorts its list into pixel spans in LDS;
 // then each wave writes its 64 rows word by word, one coalesced row at a time.  Every word of the plane is written,
 // so the plane needs no clearing.
-constexpr int kPolyMaxV = 384;                // the envelope has 361 vertices
-constexpr int kPolyCross = 32;                 // crossings kept per row (a star-shaped envelope has 2, wavy ones a few)
 __device__ __forceinline__ int span_edge(double x, int W) {
     const double a = fmin(fmax(x, -kBig), kBig);
     const int c = (int)ceil(a - 0.5);
     return c < 0 ? 0 : (c > W ? W : c);
 }
+// ROWS pixel rows per block of 128 threads, CROSS crossings kept per row: <128, 32> for the 361-vertex envelopes
+// (a star-shaped envelope has 2 crossings per row, wavy ones a few), <32, 256> for the fill polygon of the radial /
+// circular path, whose spikes can cross a row near the top or bottom tangent dozens of times.
+template <int ROWS, int CROSS>
 __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restrict__ verts, int nv, int W, int H,
                                                            int W32, uint32_t* __restrict__ planes) {
-    __shared__ double s_x[kPolyMaxV], s_y[kPolyMaxV];
     // sorted crossings of each row (+1: rows on different banks); once sorted they are converted in place to clipped
-    // pixel-span edges (int i overlays the first half of double i / 2, which has been read by then): 39 KB per block
-    __shared__ double s_xs[128][kPolyCross + 1];
-    __shared__ int s_cnt[128];
+    // pixel-span edges (int i overlays the first half of double i / 2, which has been read by then)
+    __shared__ double s_xs[ROWS][CROSS + 1];
+    __shared__ int s_cnt[ROWS];
     const int f = blockIdx.y;
-    const double* V = verts + (long)f * nv * 2;
-    for (int e = threadIdx.x; e < nv; e += 128) {
-        s_x[e] = V[2 * e];
-        s_y[e] = V[2 * e + 1];
-    }
+    const double* V = verts + (long)f * nv * 2;      // edges read their end points from global memory (L2-resident)
     // Edge-parallel crossing search: an edge crosses the sample line of row r (y = r + 0.5) iff exactly one of its end
     // points is <= it, i.e. for the rows between ceil(ymin - 0.5) and ceil(ymax - 0.5) - 1; a thread walks the few rows
     // of its edges (one candidate row more on either side, every row decided by the exact predicate, so rounding of
     // the bounds cannot change the result) and appends the crossing to the row's list.  Rows are sorted afterwards, so
-    // the append order does not matter (lists longer than kPolyCross keep an unspecified subset; envelopes have 2-6).
-    const int base = blockIdx.x * 128;
-    s_cnt[threadIdx.x] = 0;
+    // the append order does not matter (lists longer than CROSS keep an unspecified subset).
+    const int base = blockIdx.x * ROWS;
+    if (threadIdx.x < ROWS) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     for (int e = threadIdx.x; e < nv; e += 128) {
         const int ep = (e == 0) ? nv - 1 : e - 1;
-        const double x0 = s_x[ep], y0 = s_y[ep], x1 = s_x[e], y1 = s_y[e];
+        const double x0 = V[2 * ep], y0 = V[2 * ep + 1], x1 = V[2 * e], y1 = V[2 * e + 1];
         double ya = fmin(y0, y1), yb = fmax(y0, y1);
         if (!(ya == ya) || !(yb == yb)) continue;                    // NaN vertex: no crossing (comparisons are false)
         ya = fmin(fmax(ya, -kBig), kBig);
         yb = fmin(fmax(yb, -kBig), kBig);
         long ra = (long)ceil(ya - 0.5) - 1, rb = (long)ceil(yb - 0.5);
         if (ra < base) ra = base;
-        if (rb > base + 127) rb = base + 127;
+        if (rb > base + ROWS - 1) rb = base + ROWS - 1;
         if (rb > H - 1) rb = H - 1;
         for (long r = ra; r <= rb; ++r) {
             const double yc = (double)r + 0.5;
             if ((y0 <= yc) != (y1 <= yc)) {
                 const double x = x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0);
                 const int slot = atomicAdd(&s_cnt[r - base], 1);
-                if (slot < kPolyCross) s_xs[r - base][slot] = x;
+                if (slot < CROSS) s_xs[r - base][slot] = x;
             }
         }
     }
     __syncthreads();
-    int m = s_cnt[threadIdx.x];
-    if (m > kPolyCross) m = kPolyCross;
-    {
+    if (threadIdx.x < ROWS) {
+        int m = s_cnt[threadIdx.x];
+        if (m > CROSS) m = CROSS;
         double* xs = s_xs[threadIdx.x];
         for (int i = 1; i < m; ++i) {                                 // insertion sort of the row's crossings
             const double x = xs[i];
@@ -487,19 +484,20 @@ __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restr
             const int c = span_edge(xs[i], W);
             cs[i] = c;
         }
+        s_cnt[threadIdx.x] = m;
     }
-    s_cnt[threadIdx.x] = m;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wbase = threadIdx.x & 64;
-    for (int rr = 0; rr < 64; ++rr) {
-        const int row = blockIdx.x * 128 + wbase + rr;
+    // each of the two waves writes half of the block's rows, one coalesced row at a time
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int rr = wave * (ROWS / 2); rr < (wave + 1) * (ROWS / 2); ++rr) {
+        const int row = base + rr;
         if (row >= H) break;
-        const int cnt = s_cnt[wbase + rr];
+        const int cnt = s_cnt[rr];
+        const int* cs = reinterpret_cast<const int*>(s_xs[rr]);
         uint32_t* dst = planes + ((long)f * H + row) * W32;
         for (int w = lane; w < W32; w += 64) {
             uint32_t bits = 0;
             for (int i = 0; i < cnt; i += 2) {            // pixel centre px + 0.5 in [x_i, x_i+1)
-                const int* cs = reinterpret_cast<const int*>(s_xs[wbase + rr]);
                 const int c0 = cs[i], c1 = cs[i + 1];
                 const int a = c0 > 32 * w ? c0 : 32 * w;
                 const int b = c1 < 32 * w + 32 ? c1 : 32 * w + 32;
@@ -599,6 +597,22 @@ __global__ __launch_bounds__(256) void raster_fill_planes_kernel(const uint32_t*
         *dst = o;
         dst += nu4;
     }
+}
+
+// plane &= ~(excl_a | excl_b), and the whole plane of a frame is cleared when enable[f] == 0.
+__global__ __launch_bounds__(256) void plane_exclude_kernel(uint32_t* __restrict__ plane,
+                                                            const uint32_t* __restrict__ excl_a,
+                                                            const uint32_t* __restrict__ excl_b, int b_static,
+                                                            const uint8_t* __restrict__ enable, int words) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= words) return;
+    const size_t o = (size_t)f * words + i;
+    uint32_t v = plane[o];
+    if (enable != nullptr && enable[f] == 0) v = 0;
+    if (excl_a != nullptr) v &= ~excl_a[o];
+    if (excl_b != nullptr) v &= ~excl_b[b_static ? (size_t)i : o];
+    plane[o] = v;
 }
 
 // Any width (W not a multiple of 16, or an unaligned batch): one thread per pixel, three byte stores.  Same colours
@@ -885,12 +899,30 @@ extern "C" int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_verti
     if (rc) return rc;
     if ((rc = check_plane_args("aur_mask_polygon", n_frames, n_vertices, W, H))) return rc;
     if (n_frames == 0) return AUR_OK;
-    AUR_REQUIRE(n_vertices <= kPolyMaxV, "aur_mask_polygon: %d vertices > %d", n_vertices, kPolyMaxV);
     AUR_REQUIRE(d_verts && d_plane, "aur_mask_polygon: null device pointer");
     const int W32 = (W + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(mask_polygon_kernel, dim3((H + 127) / 128, n_frames), dim3(128), 0, st, d_verts, n_vertices, W,
-                       H, W32, d_plane);
+    if (n_vertices <= 384)      // envelopes and feather rings
+        hipLaunchKernelGGL((mask_polygon_kernel<128, 32>), dim3((H + 127) / 128, n_frames), dim3(128), 0, st, d_verts,
+                           n_vertices, W, H, W32, d_plane);
+    else                        // fill polygon of the radial / circular path
+        hipLaunchKernelGGL((mask_polygon_kernel<32, 256>), dim3((H + 31) / 32, n_frames), dim3(128), 0, st, d_verts,
+                           n_vertices, W, H, W32, d_plane);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_plane_exclude(aur_ctx* ctx, uint32_t* d_plane, const uint32_t* d_excl_a, const uint32_t* d_excl_b,
+                                int excl_b_static, const uint8_t* d_enable, int n_frames, int W, int H, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_plane_exclude: n_frames %d outside [0, 65535]", n_frames);
+    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_plane_exclude: frame size %dx%d unsupported", W, H);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_plane != nullptr, "aur_plane_exclude: null plane");
+    const int words = H * ((W + 31) / 32);
+    hipLaunchKernelGGL(plane_exclude_kernel, dim3((words + 255) / 256, n_frames), dim3(256), 0, (hipStream_t)stream,
+                       d_plane, d_excl_a, d_excl_b, excl_b_static ? 1 : 0, d_enable, words);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -101,6 +101,64 @@ class RadialConfig:
         return self.L1 * (1 + self.radial_smooth_amount // 25 if self.radial_smooth_amount > 0 else 1)
 
 
+def _div255(x: int) -> int:
+    return (x + (x >> 8) + 0x80) >> 8
+
+
+@dataclass
+class FillConfig:
+    """`_apply_fill` (rt_widget.py:856-864) as an export configures it (export/exporter.py:188-191): the closed path of
+    "Spectrum - Radial" / "Waveform - Circular" is filled before it is stroked when energy >= threshold."""
+    enabled: bool = False
+    rgba: tuple = (255, 255, 255, 128)       # '#80FFFFFF', exporter.py:189
+    blend: str = "normal"                    # 'normal' | 'add' | 'multiply', rt_widget.py:859-862
+    threshold: float = 0.1
+
+    @staticmethod
+    def parse_colour(text, fallback):
+        """QColor('#AARRGGBB' | '#RRGGBB'); an invalid string keeps the previous colour (rt_widget.py:369-372)."""
+        t = str(text).lstrip("#")
+        try:
+            if len(t) == 8:
+                a, r, g, b = (int(t[i:i + 2], 16) for i in (0, 2, 4, 6))
+                return (r, g, b, a)
+            if len(t) == 6:
+                r, g, b = (int(t[i:i + 2], 16) for i in (0, 2, 4))
+                return (r, g, b, 255)
+        except ValueError:
+            pass
+        return fallback
+
+    @classmethod
+    def from_view_state(cls, vs):
+        vs = vs or {}
+        c = cls()
+        c.enabled = bool(vs.get("radial_fill_enabled", False))
+        c.rgba = cls.parse_colour(vs.get("radial_fill_color", "#80FFFFFF"), (255, 255, 255, 48))   # rt_widget.py:102
+        c.blend = vs.get("radial_fill_blend", "normal") or "normal"
+        try:
+            c.threshold = float(max(0.0, min(1.0, float(vs.get("radial_fill_threshold", 0.1)))))
+        except (TypeError, ValueError):
+            c.threshold = 0.1
+        return c
+
+    def colour_over_background(self, bg=(13, 13, 18)):
+        """The fill is painted straight onto the background (paint_frame fills the frame first, rt_widget.py:829), so
+        its result is one colour: Qt's premultiplied ARGB32 SourceOver / Plus / Multiply of the fill over opaque bg."""
+        r, g, b, a = (int(v) for v in self.rgba)
+        out = []
+        for c, d in zip((r, g, b), bg):
+            s = _div255(c * a)                                   # qPremultiply
+            if self.blend == "add":
+                v = min(255, s + d)                              # comp_func_Plus
+            elif self.blend == "multiply":
+                v = _div255(s * d + d * (255 - a))               # multiply_op with an opaque destination
+            else:
+                v = s + _div255(d * (255 - a))                   # comp_func_SourceOver
+            out.append(v)
+        return tuple(out)
+
+
 def angle_table(n: int, rotation_deg: float) -> np.ndarray:
     """(cos a_i, sin a_i), a_i = 2 pi (i / n) - pi / 2 + deg2rad(rot), i = 0..n, float64 [n + 1, 2], evaluated with the
     reference's expression and scalar calls (rt_widget.py:966, :1035) -- an index-map-like table, so it is exact."""
@@ -421,6 +479,21 @@ class HipExportEngine:
             self.stream()), "aur_feather_ring_vertices")
         return rings
 
+    def apply_fill(self, fill: FillConfig, verts, sc: Scan, first: int, count: int, stroke, disc, disc_static, frames):
+        """`_apply_fill`: the polygon of the closed path ``verts`` in the fill's colour wherever neither the stroke nor the
+        disc paints afterwards, in the frames whose energy reaches the threshold (in place on ``frames``)."""
+        torch = self.torch
+        H, W = int(frames.shape[1]), int(frames.shape[2])
+        W32 = (W + 31) // 32
+        h, st = self.ctx.handle, self.stream()
+        plane = self.empty((count, 1, H, W32), torch.int32)
+        _lib.check(self.lib.aur_mask_polygon(h, _ptr(verts), int(verts.shape[1]), count, W, H, _ptr(plane), st),
+                   "aur_mask_polygon")
+        enable = (sc.energy[first:first + count] >= float(fill.threshold)).to(torch.uint8)     # rt_widget.py:857
+        _lib.check(self.lib.aur_plane_exclude(h, _ptr(plane), _ptr(stroke), _ptr(disc), int(bool(disc_static)),
+                                              _ptr(enable), count, W, H, st), "aur_plane_exclude")
+        return self.blend_planes(plane, bytes(fill.colour_over_background()) + b"\xff", frames)
+
     # QColor(13, 13, 18) with alpha max(10, 70 - 10 k), k = 1..6 (rt_widget.py:1099, :1116)
     FEATHER_RGBA = bytes(v for k in range(1, 7) for v in (13, 13, 18, max(10, 70 - 10 * k)))
     DISC_RGBA = bytes((30, 30, 40, 255))                                    # rt_widget.py:1092/1094
@@ -501,12 +574,15 @@ class HipExportEngine:
         return out
 
     def render_radial(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int = 0,
-                      count: int | None = None, out=None, planes_out=None):
+                      count: int | None = None, out=None, planes_out=None, fill: FillConfig | None = None):
         """Frames uint8 [count, H, W, 3] of "Spectrum - Radial" (paint_frame, rt_widget.py:821-852)."""
         if count is None:
             count = an.n_frames - first
         planes = self.radial_planes(prep, an, sc, W, H, first, count, planes_out)
         out = self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
+        if fill is not None and fill.enabled:
+            verts = self.radial_path_vertices(prep, sc, W, H, first, count)
+            self.apply_fill(fill, verts, sc, first, count, planes[0], planes[1], planes[2], out)
         if prep.cfg.feather_enabled:
             self.feather_blend(prep, an, sc, W, H, first, count, out)
         return out
@@ -541,12 +617,16 @@ class HipExportEngine:
         return stroke, self._col2samp[key], True
 
     def render_wave_circular(self, an: Analysis, sc: Scan, W: int, H: int, first: int = 0, count: int | None = None,
-                             rotation_deg: float = 0.0, out=None, planes_out=None):
+                             rotation_deg: float = 0.0, out=None, planes_out=None, fill: FillConfig | None = None):
         """Frames uint8 [count, H, W, 3] of "Waveform - Circular" (paint_frame, rt_widget.py:821-852)."""
         if count is None:
             count = an.n_frames - first
         planes = self.wave_circular_planes(an, sc, W, H, first, count, rotation_deg, planes_out)
-        return self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
+        out = self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
+        if fill is not None and fill.enabled:
+            verts = self.wave_circular_vertices(an, sc, W, H, first, count, rotation_deg)
+            self.apply_fill(fill, verts, sc, first, count, planes[0], None, True, out)
+        return out
 
     # ------------------------------------------------------------------ streaming Analyzer step
     def stft_buffer(self, d_buffer, d_prev_mag, d_logspec, d_flux_sum):

@@ -243,12 +243,22 @@ int aur_wave_circular_vertices(aur_ctx* ctx, const float* d_samples, const doubl
  * aur_mask_stroke_closed: width-2 BevelJoin stroke of the closed polygon through d_verts [F, n_vertices, 2]
  *   (`p.drawPath(path)` with the width-2 pen, rt_widget.py:975-981);
  * aur_mask_polygon: even-odd fill of the implicitly closed polygon, sampled at pixel centres
- *   (`p.fillPath(path, QColor(30,30,40))` under the clip, rt_widget.py:1056-1096; edge antialiasing not reproduced).
+ *   (`p.fillPath(path, QColor(30,30,40))` under the clip, rt_widget.py:1056-1096; edge antialiasing not reproduced);
+ *   up to 32 crossings per pixel row are kept for polygons of at most 384 vertices (envelopes, feather rings), up to
+ *   256 for longer ones (the fill polygon of the radial / circular path, rt_widget.py:856-864).
  * Both overwrite the whole plane. */
 int aur_mask_stroke_closed(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
                            uint32_t* d_plane, void* stream);
 int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
                      uint32_t* d_plane, void* stream);
+
+/* d_plane &= ~(d_excl_a | d_excl_b) per frame (either may be NULL; excl_b_static != 0: one plane for all frames), and the
+ * plane of frame f is cleared when d_enable != NULL and d_enable[f] == 0.  Used for `_apply_fill` (rt_widget.py:856-864,
+ * called at :898 and :977 before the path is stroked and before the centre disc): the fill polygon of the closed path
+ * only shows where neither the stroke nor the disc paints later, and only in frames with energy >= threshold; its
+ * colour over the plain background is a per-export constant, applied with aur_blend_planes. */
+int aur_plane_exclude(aur_ctx* ctx, uint32_t* d_plane, const uint32_t* d_excl_a, const uint32_t* d_excl_b,
+                      int excl_b_static, const uint8_t* d_enable /*[F]*/, int n_frames, int W, int H, void* stream);
 
 /* RGB24 frames of "Spectrum - Radial" / "Waveform - Circular" (paint_frame, rt_widget.py:821-852): background
  * (13,13,18), stroke plane in the pen colour, disc plane in (30,30,40) on top (an all-zero static plane when the mode

@@ -403,7 +403,7 @@ def stroke_mask_closed(verts, w, h):
     return mask
 
 
-def polygon_mask(verts, w, h):
+def polygon_mask(verts, w, h, max_cross=None):
     """Bit plane of the even-odd fill of the (implicitly closed) polygon ``verts``, sampled at pixel centres."""
     V = np.asarray(verts, dtype=np.float64)
     n = V.shape[0]
@@ -416,8 +416,8 @@ def polygon_mask(verts, w, h):
             x1, y1 = V[(e + 1) % n]
             if (y0 <= yc) != (y1 <= yc):
                 xs.append(x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0))
-        xs.sort()       # the kernel keeps at most 32 crossings per row; envelopes stay far below that
-        assert len(xs) <= 32
+        xs.sort()       # the kernel keeps at most 32 crossings per row; envelopes and smoothed rings stay below that
+        assert len(xs) <= (max_cross or (32 if n <= 384 else 256))
         for i in range(0, len(xs) - 1, 2):
             a = min(max(xs[i], -_BIG), _BIG)
             b = min(max(xs[i + 1], -_BIG), _BIG)
@@ -442,13 +442,32 @@ def blend_solid(frame, mask_bool, rgb, alpha):
     frame[mask_bool] = (_div255(c * a) + _div255(d * (np.uint32(255) - a))).astype(np.uint8)
 
 
-def render_radial_frame(path_verts, env_verts, pen_rgb, w, h, bg=BG, rings=None):
+def fill_colour_over_background(rgba, blend="normal", bg=BG):
+    """Result of `p.fillPath(path, fill_color)` on the plain background for the three blends of `_apply_fill`
+    (rt_widget.py:856-864): Qt premultiplied ARGB32 SourceOver / Plus / Multiply over an opaque destination."""
+    r, g, b, a = (int(v) for v in rgba)
+    out = []
+    for c, d in zip((r, g, b), bg):
+        s = int(_div255(c * a))
+        if blend == "add":
+            out.append(min(255, s + d))
+        elif blend == "multiply":
+            out.append(int(_div255(s * d + d * (255 - a))))
+        else:
+            out.append(s + int(_div255(d * (255 - a))))
+    return tuple(out)
+
+
+def render_radial_frame(path_verts, env_verts, pen_rgb, w, h, bg=BG, rings=None, fill_rgb=None):
     """One "Spectrum - Radial" frame: background, radial stroke in the pen colour, centre disc on top, then the
     feather rings ``[(vertices, alpha)]`` (radial_ref.feather_ring_paths) blended in order."""
     frame = np.empty((h, w, 3), dtype=np.uint8)
     frame[:] = np.asarray(bg, dtype=np.uint8)
+    if fill_rgb is not None:                 # `_apply_fill` comes first (rt_widget.py:977)
+        frame[unpack_mask(polygon_mask(path_verts, w, h), w)] = np.asarray(fill_rgb, dtype=np.uint8)
     frame[unpack_mask(stroke_mask_closed(path_verts, w, h), w)] = np.asarray(pen_rgb, dtype=np.uint8)
-    frame[unpack_mask(polygon_mask(env_verts, w, h), w)] = np.asarray(DISC_RGB, dtype=np.uint8)
+    if env_verts is not None:
+        frame[unpack_mask(polygon_mask(env_verts, w, h), w)] = np.asarray(DISC_RGB, dtype=np.uint8)
     for verts, alpha in (rings or []):
         blend_solid(frame, unpack_mask(polygon_mask(verts, w, h), w), bg, alpha)
     return frame

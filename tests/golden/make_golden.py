@@ -159,6 +159,7 @@ class QPainter:
     def drawPath(self, path): self.calls.append(("drawPath", list(path.ops)))
     def fillPath(self, path, col): self.calls.append(("fillPath", list(path.ops), col.tup()))
     def setClipPath(self, path): self.calls.append(("setClipPath", list(path.ops)))
+    def setCompositionMode(self, mode): self.calls.append(("setCompositionMode", int(mode)))
     def save(self): self.calls.append(("save",))
     def restore(self): self.calls.append(("restore",))
 
@@ -364,7 +365,54 @@ def capture_wave_circular(name, kind, n, sr, fps, sizes, frames, view_state, sen
     print(f"wavecirc_{name}: {len(out)} arrays")
 
 
+def capture_fill(name, mode, kind, n, sr, fps, size, view_state, sensitivity=1.0):
+    """`_apply_fill` (rt_widget.py:856-864): for EVERY frame whether fillPath was called, its colour, the composition
+    mode set before it and the position of the call among the others; fill path vertices of a few frames."""
+    from export.exporter import QPainterOffscreenRenderer
+    audio = _track(kind, n, sr, 2)
+    path = f"mem://fill_{name}"
+    _AUDIO[path] = (audio, sr)
+    w, h = size
+    r = QPainterOffscreenRenderer(w, h, mode, (0.2, 0.8, 1.0), sensitivity, fps, path, **view_state)
+    total = int(np.ceil(r.duration * fps))
+    filled = np.zeros(total, np.uint8)
+    comp = np.full(total, -1, np.int64)
+    rgba = np.zeros((total, 4), np.int64)
+    out = dict(audio=audio, sample_rate=sr, fps=fps, size=np.asarray(size), sensitivity=sensitivity, mode=np.asarray(mode),
+               view_state_json=np.asarray(__import__("json").dumps(view_state)))
+    for i in range(total):
+        s, spec = r._read_frame(i / fps)
+        calls = r._view.render_frame_to_qimage(w, h, s, spec).calls
+        names = [c[0] for c in calls]
+        fills = [c for c in calls if c[0] == "fillPath" and c[2][:3] != (30, 30, 40)]
+        if fills:
+            assert len(fills) == 1
+            filled[i] = 1
+            rgba[i] = fills[0][2]
+            k = names.index("fillPath")
+            assert k < names.index("drawPath")                       # the fill comes before the stroke
+            cm = [c for c in calls[:k] if c[0] == "setCompositionMode"]
+            comp[i] = cm[-1][1] if cm else -1
+            dp = [c for c in calls if c[0] == "drawPath"][0]
+            assert fills[0][1] == dp[1]                               # same path object
+            if i < 6:
+                out[f"f{i}_path"] = _path_xy(fills[0][1])
+    out.update(filled=filled, comp=comp, rgba=rgba)
+    np.savez_compressed(os.path.join(HERE, f"fill_{name}.npz"), **out)
+    print(f"fill_{name}: {int(filled.sum())}/{total} frames filled, rgba {rgba[filled > 0][:1].tolist()}")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "fill":           # adds the fill_* fixtures only
+        _install_stand_ins()
+        sys.path.insert(0, REF)
+        # thresholds inside the energy range of the track, so that some frames are filled and some are not
+        capture_fill("radial_normal", "Spectrum - Radial", "pink", 24000, 48000, 60, (640, 368),
+                     dict(radial_fill_enabled=True, radial_fill_threshold=0.087))
+        capture_fill("circular_add", "Waveform - Circular", "pink", 24000, 48000, 60, (640, 368),
+                     dict(radial_fill_enabled=True, radial_fill_color="#6040C0FF", radial_fill_blend="add",
+                          radial_fill_threshold=0.07), sensitivity=0.8)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "wave_circular":  # adds the wavecirc_* fixtures only
         _install_stand_ins()
         sys.path.insert(0, REF)

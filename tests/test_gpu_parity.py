@@ -690,3 +690,45 @@ def test_degenerate_track_lengths(eng, n):
         assert np.array_equal(_np(an.samples), ref["samples"])
         assert np.array_equal(_np(sc.energy), ref["energy"])
         assert np.allclose(_np(an.logspec), ref["logspec"], rtol=1e-4, atol=2e-6)
+
+
+# ------------------------------------------------------------------ fill decoration (`_apply_fill`)
+
+@pytest.mark.parametrize("mode,vs", [
+    ("Spectrum - Radial", dict(radial_fill_enabled=True, radial_fill_threshold=0.087)),
+    ("Spectrum - Radial", dict(radial_fill_enabled=True, radial_fill_threshold=0.0, radial_fill_blend="multiply",
+                               radial_fill_color="#C0FF8040", radial_smooth_amount=0, radial_waveform_smoothness=0,
+                               radial_temporal_smoothing=0, radial_mirror=True)),
+    ("Waveform - Circular", dict(radial_fill_enabled=True, radial_fill_color="#6040C0FF", radial_fill_blend="add",
+                                 radial_fill_threshold=0.07, radial_rotation_deg=20.0)),
+])
+def test_fill_decoration_raster_bit_exact(eng, mode, vs):
+    from aurora_amd import synth
+    from aurora_amd.engine import FillConfig
+    from aurora_amd.pipeline import FramePipeline
+    from oracle import radial_ref as RR
+    W, H, sr, fps = 640, 368, 48000, 60
+    audio = synth.pink(9000, 2, seed=1234)
+    track = eng.upload_track(audio, sr, fps)
+    fc = FillConfig.from_view_state(vs)
+    radial = _radial_cfg(vs) if "Radial" in mode else None
+    rot = float(vs.get("radial_rotation_deg", 0.0))
+    pipe = FramePipeline(eng, track, mode, W, H, radial=radial, rotation_deg=rot, fill=fc)
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    energy, pen = _np(sc.energy), _np(sc.pen_rgb)[:, :3]
+    rgb = R.fill_colour_over_background(fc.rgba, fc.blend)
+    if radial is not None:
+        verts, env = eng.radial_vertices(pipe._radial_prep, an, sc, W, H, 0, an.n_frames)
+        verts, env = _np(verts), _np(env)
+    else:
+        verts, env = _np(eng.wave_circular_vertices(an, sc, W, H, 0, an.n_frames, rot)), None
+    n_filled = 0
+    for f in range(an.n_frames):
+        on = energy[f] >= fc.threshold
+        n_filled += int(on)
+        want = R.render_radial_frame(verts[f], None if env is None else env[f], pen[f], W, H,
+                                     fill_rgb=rgb if on else None)
+        assert np.array_equal(frames[f], want), (mode, f, int(np.sum(frames[f] != want)))
+    assert n_filled > 0
+    assert (frames == np.array(rgb, np.uint8)).all(axis=3).sum() > 1000 * n_filled

@@ -222,3 +222,43 @@ def test_wave_circular_paths_match_reference(fixture):
             assert list(g[key + "_calls"]) == ['fillRect', 'setPen', 'drawPath', 'end']
             seen += 1
     assert seen == len(g["sizes"]) * len(g["frames"])
+
+
+@pytest.mark.parametrize("fixture", ["fill_radial_normal", "fill_circular_add"])
+def test_fill_decoration_matches_reference_calls(fixture):
+    """`_apply_fill` (rt_widget.py:856-864): frames the reference filled == frames with energy >= threshold, the colour
+    it passed == the host's parse of the view_state string, the fill path == the stroked path (oracle vertices)."""
+    import json
+    from aurora_amd.engine import FillConfig
+    from oracle import radial_ref as RR
+    g = load_golden(fixture)
+    audio, sr, fps = g["audio"], int(g["sample_rate"]), int(g["fps"])
+    sens = float(g["sensitivity"])
+    vs = json.loads(str(g["view_state_json"]))
+    W, H = (int(v) for v in g["size"])
+    ref = A.analyze_track(audio, sr, fps, sensitivity=sens)
+    fc = FillConfig.from_view_state(vs)
+    assert fc.enabled
+    assert np.array_equal(ref["energy"] >= fc.threshold, g["filled"].astype(bool))
+    assert 0 < int(g["filled"].sum()) < len(g["filled"])
+    for i in np.nonzero(g["filled"])[0]:
+        assert tuple(int(v) for v in g["rgba"][i]) == tuple(fc.rgba)
+        # CompositionMode_Plus = 12, _Multiply = 13 in the recording painter; -1 = not set (normal)
+        assert int(g["comp"][i]) == {"normal": -1, "add": 12, "multiply": 13}[fc.blend]
+    assert R.fill_colour_over_background(fc.rgba, fc.blend) == fc.colour_over_background()
+    mode = str(g["mode"])
+    tr = RR.RadialTrack(RR.RadialParams.from_view_state(vs, sens))
+    for f in range(ref["samples"].shape[0]):
+        e = float(ref["energy"][f])
+        path = (tr.path(ref["logspec"][f], e, W, H) if "Radial" in mode
+                else RR.wave_circular_path(ref["samples"][f], e, W, H, float(vs.get("radial_rotation_deg", 0.0))))
+        if f"f{f}_path" in g.files:
+            assert np.array_equal(path, g[f"f{f}_path"]), f
+
+
+def test_fill_colour_composition_rules():
+    # '#80FFFFFF' over (13, 13, 18): SourceOver = div255(255*128) + div255(d*127)
+    assert R.fill_colour_over_background((255, 255, 255, 128), "normal") == (128 + 6, 128 + 6, 128 + 9)
+    assert R.fill_colour_over_background((255, 255, 255, 128), "add") == (141, 141, 146)
+    assert R.fill_colour_over_background((255, 255, 255, 255), "multiply") == (13, 13, 18)
+    assert R.fill_colour_over_background((0, 0, 0, 0), "normal") == (13, 13, 18)

@@ -378,13 +378,18 @@ __device__ __forceinline__ bool seg_dir(const double* V, int n, int s, double& u
     return true;
 }
 
-// Width-2 BevelJoin stroke of the closed polygon verts[f][nv][2]: thread t < nv draws segment t, thread nv + t the
-// bevel at vertex t.  The plane must be zero on entry.
+// BevelJoin stroke of half-width hw (1 for the width-2 pen) of the closed polygon verts[f][nv][2] translated by (tx, ty):
+// thread t < nv draws segment t, thread nv + t the bevel at vertex t.  The plane must be zero on entry.  hw = 1 and
+// tx = ty = 0 reproduce the untranslated width-2 stroke bit for bit (x + 0 and n * 1 are exact).
 __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* __restrict__ verts, int nv, int W, int H,
-                                                                 int W32, uint32_t* __restrict__ planes) {
+                                                                 int W32, double hw, double tx, double ty,
+                                                                 int closed, uint32_t* __restrict__ planes) {
+    // closed == 0: open polyline (the envelope path of `_draw_center_image_and_mask` has no closeSubpath): no segment
+    // from the last vertex to the first, no join at either end, SquareCap = the end segments extended by hw.
     const int f = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= 2 * nv) return;
+    if (!closed && (t == nv - 1 || t == nv || t == 2 * nv - 1)) return;
     const double* V = verts + (long)f * nv * 2;
     uint32_t* plane = planes + (long)f * H * W32;
     double px[4], py[4];
@@ -392,8 +397,16 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
         double ux, uy;
         if (!seg_dir(V, nv, t, ux, uy)) return;
         const int t1 = (t + 1 == nv) ? 0 : t + 1;
-        const double ax = V[2 * t], ay = V[2 * t + 1], bx = V[2 * t1], by = V[2 * t1 + 1];
-        const double nx = -uy, ny = ux;
+        double ax = V[2 * t] + tx, ay = V[2 * t + 1] + ty, bx = V[2 * t1] + tx, by = V[2 * t1 + 1] + ty;
+        if (!closed && t == 0) {
+            ax = ax - ux * hw;
+            ay = ay - uy * hw;
+        }
+        if (!closed && t == nv - 2) {
+            bx = bx + ux * hw;
+            by = by + uy * hw;
+        }
+        const double nx = -uy * hw, ny = ux * hw;
         px[0] = ax + nx; py[0] = ay + ny;
         px[1] = bx + nx; py[1] = by + ny;
         px[2] = bx - nx; py[2] = by - ny;
@@ -407,10 +420,10 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
         const double cr = uxa * uyb - uya * uxb;
         if (cr == 0.0) return;
         const double sg = (cr > 0.0) ? -1.0 : 1.0;
-        const double vx = V[2 * v], vy = V[2 * v + 1];
+        const double vx = V[2 * v] + tx, vy = V[2 * v + 1] + ty;
         px[0] = vx; py[0] = vy;
-        px[1] = vx + sg * (-uya); py[1] = vy + sg * uxa;
-        px[2] = vx + sg * (-uyb); py[2] = vy + sg * uxb;
+        px[1] = vx + sg * (-uya) * hw; py[1] = vy + sg * uxa * hw;
+        px[2] = vx + sg * (-uyb) * hw; py[2] = vy + sg * uxb * hw;
         raster_convex(plane, W32, px, py, 3, W, H);
     }
 }
@@ -879,16 +892,26 @@ static int check_plane_args(const char* who, int n_frames, int nv, int W, int H)
 
 extern "C" int aur_mask_stroke_closed(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
                                       uint32_t* d_plane, void* stream) {
+    return aur_mask_stroke_path(ctx, d_verts, n_vertices, n_frames, W, H, 1.0, 0.0, 0.0, 1, d_plane, stream);
+}
+
+extern "C" int aur_mask_stroke_path(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
+                                    double half_width, double dx, double dy, int closed, uint32_t* d_plane,
+                                    void* stream) {
     int rc = aur_use_device(ctx);
     if (rc) return rc;
     if ((rc = check_plane_args("aur_mask_stroke_closed", n_frames, n_vertices, W, H))) return rc;
+    AUR_REQUIRE(half_width > 0.0 && half_width <= 256.0, "aur_mask_stroke_closed: half width %g outside (0, 256]",
+                half_width);
+    AUR_REQUIRE(dx == dx && dy == dy && fabs(dx) <= 65536.0 && fabs(dy) <= 65536.0,
+                "aur_mask_stroke_closed: translation (%g, %g) out of range", dx, dy);
     if (n_frames == 0) return AUR_OK;
     AUR_REQUIRE(d_verts && d_plane, "aur_mask_stroke_closed: null device pointer");
     const int W32 = (W + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     AUR_CHECK_HIP(hipMemsetAsync(d_plane, 0, (size_t)n_frames * H * W32 * 4, st));
     hipLaunchKernelGGL(mask_stroke_closed_kernel, dim3((2 * n_vertices + 255) / 256, n_frames), dim3(256), 0, st,
-                       d_verts, n_vertices, W, H, W32, d_plane);
+                       d_verts, n_vertices, W, H, W32, half_width, dx, dy, closed ? 1 : 0, d_plane);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

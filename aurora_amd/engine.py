@@ -159,6 +159,51 @@ class FillConfig:
         return tuple(out)
 
 
+@dataclass
+class ShadowConfig:
+    """`_draw_shadow_path` (rt_widget.py:579-594) as an export configures it (export/exporter.py:212-223; widget
+    defaults rt_widget.py:80-85).  Closed paths only ("Spectrum - Radial", "Waveform - Circular")."""
+    enabled: bool = False
+    opacity: float = 0.6
+    blur: int = 16
+    distance: int = 8
+    angle_deg: int = 45
+
+    @classmethod
+    def from_view_state(cls, vs):
+        vs = vs or {}
+        c = cls()
+        if "shadow_enabled" in vs:
+            c.enabled = bool(vs["shadow_enabled"])
+        if "shadow_opacity" in vs:
+            c.opacity = max(0.0, min(1.0, int(vs["shadow_opacity"]) / 100.0))          # rt_widget.py:302-304
+        if "shadow_blur_radius" in vs:
+            c.blur = int(max(0, int(vs["shadow_blur_radius"])))
+        if "shadow_distance" in vs:
+            c.distance = int(max(0, int(vs["shadow_distance"])))
+        if "shadow_angle_deg" in vs:
+            c.angle_deg = int(vs["shadow_angle_deg"])
+        return c
+
+    @property
+    def active(self):
+        return self.enabled and self.opacity > 0.0                                       # rt_widget.py:580
+
+    @property
+    def alpha(self):
+        return int(255 * self.opacity)                                                   # :582
+
+    @property
+    def offset(self):
+        import math
+        ang, dist = float(self.angle_deg), float(max(0.0, self.distance))
+        return dist * math.cos(math.radians(ang)), dist * math.sin(math.radians(ang))    # :584-587
+
+    @property
+    def half_width(self):
+        return max(2, self.blur) / 2.0                                                   # pen.setWidth(max(2, blur)), :591
+
+
 def angle_table(n: int, rotation_deg: float) -> np.ndarray:
     """(cos a_i, sin a_i), a_i = 2 pi (i / n) - pi / 2 + deg2rad(rot), i = 0..n, float64 [n + 1, 2], evaluated with the
     reference's expression and scalar calls (rt_widget.py:966, :1035) -- an index-map-like table, so it is exact."""
@@ -494,6 +539,23 @@ class HipExportEngine:
                                               _ptr(enable), count, W, H, st), "aur_plane_exclude")
         return self.blend_planes(plane, bytes(fill.colour_over_background()) + b"\xff", frames)
 
+    def apply_shadow(self, shadow: ShadowConfig, verts, closed: bool, excl_a, excl_b, excl_b_static, frames):
+        """`_draw_shadow_path` of ``verts`` float64 [count, n, 2]: translated wide stroke in QColor(0, 0, 0, alpha),
+        source-over on the frame wherever the planes ``excl_a`` / ``excl_b`` (what the reference paints afterwards
+        with opaque colours) have no bit (in place)."""
+        torch = self.torch
+        count, H, W = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+        W32 = (W + 31) // 32
+        h, st = self.ctx.handle, self.stream()
+        plane = self.empty((count, 1, H, W32), torch.int32)
+        dx, dy = shadow.offset
+        _lib.check(self.lib.aur_mask_stroke_path(h, _ptr(verts), int(verts.shape[1]), count, W, H,
+                                                 float(shadow.half_width), float(dx), float(dy), int(bool(closed)),
+                                                 _ptr(plane), st), "aur_mask_stroke_path")
+        _lib.check(self.lib.aur_plane_exclude(h, _ptr(plane), _ptr(excl_a), _ptr(excl_b), int(bool(excl_b_static)),
+                                              None, count, W, H, st), "aur_plane_exclude")
+        return self.blend_planes(plane, bytes((0, 0, 0, shadow.alpha)), frames)
+
     # QColor(13, 13, 18) with alpha max(10, 70 - 10 k), k = 1..6 (rt_widget.py:1099, :1116)
     FEATHER_RGBA = bytes(v for k in range(1, 7) for v in (13, 13, 18, max(10, 70 - 10 * k)))
     DISC_RGBA = bytes((30, 30, 40, 255))                                    # rt_widget.py:1092/1094
@@ -574,15 +636,25 @@ class HipExportEngine:
         return out
 
     def render_radial(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int = 0,
-                      count: int | None = None, out=None, planes_out=None, fill: FillConfig | None = None):
-        """Frames uint8 [count, H, W, 3] of "Spectrum - Radial" (paint_frame, rt_widget.py:821-852)."""
+                      count: int | None = None, out=None, planes_out=None, fill: FillConfig | None = None,
+                      shadow: ShadowConfig | None = None):
+        """Frames uint8 [count, H, W, 3] of "Spectrum - Radial" (paint_frame, rt_widget.py:821-852).  The reference's
+        order is fill, path shadow, stroke, envelope shadow, disc, feather rings; stroke and disc are opaque, so the
+        translucent layers are applied afterwards where those two do not cover them."""
         if count is None:
             count = an.n_frames - first
         planes = self.radial_planes(prep, an, sc, W, H, first, count, planes_out)
         out = self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
-        if fill is not None and fill.enabled:
+        want_fill = fill is not None and fill.enabled
+        want_shadow = shadow is not None and shadow.active
+        if want_fill or want_shadow:
             verts = self.radial_path_vertices(prep, sc, W, H, first, count)
+        if want_fill:
             self.apply_fill(fill, verts, sc, first, count, planes[0], planes[1], planes[2], out)
+        if want_shadow:
+            self.apply_shadow(shadow, verts, True, planes[0], planes[1], planes[2], out)          # :978-979
+            env = self._envelope(prep, an, sc, W, H, first, count)
+            self.apply_shadow(shadow, env, False, None, planes[1], planes[2], out)                # :1053-1054
         if prep.cfg.feather_enabled:
             self.feather_blend(prep, an, sc, W, H, first, count, out)
         return out
@@ -617,15 +689,21 @@ class HipExportEngine:
         return stroke, self._col2samp[key], True
 
     def render_wave_circular(self, an: Analysis, sc: Scan, W: int, H: int, first: int = 0, count: int | None = None,
-                             rotation_deg: float = 0.0, out=None, planes_out=None, fill: FillConfig | None = None):
+                             rotation_deg: float = 0.0, out=None, planes_out=None, fill: FillConfig | None = None,
+                             shadow: ShadowConfig | None = None):
         """Frames uint8 [count, H, W, 3] of "Waveform - Circular" (paint_frame, rt_widget.py:821-852)."""
         if count is None:
             count = an.n_frames - first
         planes = self.wave_circular_planes(an, sc, W, H, first, count, rotation_deg, planes_out)
         out = self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
-        if fill is not None and fill.enabled:
+        want_fill = fill is not None and fill.enabled
+        want_shadow = shadow is not None and shadow.active
+        if want_fill or want_shadow:
             verts = self.wave_circular_vertices(an, sc, W, H, first, count, rotation_deg)
-            self.apply_fill(fill, verts, sc, first, count, planes[0], None, True, out)
+        if want_fill:
+            self.apply_fill(fill, verts, sc, first, count, planes[0], None, True, out)            # :898
+        if want_shadow:
+            self.apply_shadow(shadow, verts, True, planes[0], None, True, out)                    # :899-900
         return out
 
     # ------------------------------------------------------------------ streaming Analyzer step

@@ -19,7 +19,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from .engine import FillConfig, HipExportEngine, PLANE_KINDS, RadialConfig, Track, mode_kind, SUPPORTED_KINDS
+from .engine import FillConfig, ShadowConfig, HipExportEngine, PLANE_KINDS, RadialConfig, Track, mode_kind, SUPPORTED_KINDS
 
 
 class NullSink:
@@ -71,7 +71,7 @@ class FramePipeline:
                  sensitivity: float = 1.0, frame_begin: int = 0, frame_end: int | None = None,
                  batch_frames: int | None = None, slots: int = 2, scan_params: _lib.ScanParams | None = None,
                  radial: "RadialConfig | None" = None, rotation_deg: float = 0.0, wire_format: str = "rgb24",
-                 fill: "FillConfig | None" = None):
+                 fill: "FillConfig | None" = None, shadow: "ShadowConfig | None" = None):
         self.eng = engine
         self.track = track
         self.mode = mode
@@ -98,6 +98,11 @@ class FramePipeline:
         self.rotation_deg = float(rotation_deg)          # radial_rotation_deg, used by "Waveform - Circular" too
         self.planes = self.kind in PLANE_KINDS
         self.fill = fill if (fill is not None and fill.enabled and self.planes) else None    # `_apply_fill`: closed paths only
+        # the reference draws no shadow for the bar spectrum or the particles; the linear waveform has its own
+        # RoundCap / RoundJoin variant (rt_widget.py:915-930), which is not built
+        if shadow is not None and shadow.active and self.kind == "waveform_linear":
+            raise NotImplementedError("shadow of 'Waveform - Linear' is not implemented on the HIP path")
+        self.shadow = shadow if (shadow is not None and shadow.active and self.planes) else None
         self._analysed = None
         self._radial_prep = None
 
@@ -123,10 +128,10 @@ class FramePipeline:
     def _render(self, an, sc, first, count, out=None, scratch=None):
         if self.radial is not None:
             return self.eng.render_radial(self._radial_prep, an, sc, self.W, self.H, first, count, out=out,
-                                          planes_out=scratch, fill=self.fill)
+                                          planes_out=scratch, fill=self.fill, shadow=self.shadow)
         if self.kind == "waveform_circular":
             return self.eng.render_wave_circular(an, sc, self.W, self.H, first, count, self.rotation_deg, out=out,
-                                                 planes_out=scratch, fill=self.fill)
+                                                 planes_out=scratch, fill=self.fill, shadow=self.shadow)
         return self.eng.render(self.mode, an, sc, self.W, self.H, first, count, out=out, spans_out=scratch)
 
     # ---- full pipeline: GPU -> pinned host ring -> sink --------------------------------------------------

@@ -251,6 +251,13 @@ int aur_mask_stroke_closed(aur_ctx* ctx, const double* d_verts, int n_vertices, 
                            uint32_t* d_plane, void* stream);
 int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
                      uint32_t* d_plane, void* stream);
+/* Stroke of half width `half_width` (pen width / 2) of the path translated by (dx, dy), closed or open:
+ * `_draw_shadow_path` (rt_widget.py:579-594) strokes a path with a QPen of width max(2, shadow_blur), default
+ * SquareCap / BevelJoin, after `p.translate(dist cos(angle), dist sin(angle))`; the radial / circular paths end with
+ * closeSubpath, the envelope path of the centre disc does not (closed = 0: no closing segment, no join at the ends,
+ * square caps).  half_width = 1, dx = dy = 0, closed = 1 is aur_mask_stroke_closed bit for bit. */
+int aur_mask_stroke_path(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
+                         double half_width, double dx, double dy, int closed, uint32_t* d_plane, void* stream);
 
 /* d_plane &= ~(d_excl_a | d_excl_b) per frame (either may be NULL; excl_b_static != 0: one plane for all frames), and the
  * plane of frame f is cleared when d_enable != NULL and d_enable[f] == 0.  Used for `_apply_fill` (rt_widget.py:856-864,

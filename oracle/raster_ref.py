@@ -370,8 +370,9 @@ def _raster_convex(mask, px, py, w, h):
         _or_span(mask, r, math.ceil(xmin - 0.5), math.floor(xmax - 0.5) + 1, w)
 
 
-def stroke_mask_closed(verts, w, h):
-    """Bit plane of a width-2 BevelJoin stroke of the closed polygon through ``verts`` float64[n, 2]."""
+def stroke_mask_closed(verts, w, h, half_width=1.0, dx=0.0, dy=0.0, closed=True):
+    """Bit plane of a BevelJoin stroke (pen width 2 * half_width) of the polygon through ``verts`` float64[n, 2]
+    translated by (dx, dy); closed=False: open polyline with SquareCap ends (`_draw_shadow_path` of the envelope)."""
     import math as _m
     V = np.asarray(verts, dtype=np.float64)
     n = V.shape[0]
@@ -379,18 +380,27 @@ def stroke_mask_closed(verts, w, h):
     ux = np.zeros(n)
     uy = np.zeros(n)
     ok = np.zeros(n, dtype=bool)
+    hw, tx, ty = float(half_width), float(dx), float(dy)
     for s in range(n):                       # segment s: V[s] -> V[(s + 1) % n]
-        ax, ay = V[s]
-        bx, by = V[(s + 1) % n]
-        dx, dy = bx - ax, by - ay
-        ln = _m.sqrt(dx * dx + dy * dy)
+        ex, ey = V[(s + 1) % n][0] - V[s][0], V[(s + 1) % n][1] - V[s][1]
+        ln = _m.sqrt(ex * ex + ey * ey)
         if ln == 0.0:
             continue
         ok[s] = True
-        ux[s], uy[s] = dx / ln, dy / ln
-        nx, ny = -uy[s], ux[s]
+        ux[s], uy[s] = ex / ln, ey / ln
+        if not closed and s == n - 1:
+            continue
+        ax, ay = V[s][0] + tx, V[s][1] + ty
+        bx, by = V[(s + 1) % n][0] + tx, V[(s + 1) % n][1] + ty
+        if not closed and s == 0:            # SquareCap: the end segments are extended by the half width
+            ax, ay = ax - ux[s] * hw, ay - uy[s] * hw
+        if not closed and s == n - 2:
+            bx, by = bx + ux[s] * hw, by + uy[s] * hw
+        nx, ny = -uy[s] * hw, ux[s] * hw
         _raster_convex(mask, [ax + nx, bx + nx, bx - nx, ax - nx], [ay + ny, by + ny, by - ny, ay - ny], w, h)
     for v in range(n):                       # bevel at V[v] between segments v-1 and v
+        if not closed and (v == 0 or v == n - 1):
+            continue
         a, b = (v - 1) % n, v
         if not (ok[a] and ok[b]):
             continue
@@ -398,8 +408,9 @@ def stroke_mask_closed(verts, w, h):
         if cr == 0.0:
             continue
         sg = -1.0 if cr > 0.0 else 1.0
-        vx, vy = V[v]
-        _raster_convex(mask, [vx, vx + sg * (-uy[a]), vx + sg * (-uy[b])], [vy, vy + sg * ux[a], vy + sg * ux[b]], w, h)
+        vx, vy = V[v][0] + tx, V[v][1] + ty
+        _raster_convex(mask, [vx, vx + sg * (-uy[a]) * hw, vx + sg * (-uy[b]) * hw],
+                       [vy, vy + sg * ux[a] * hw, vy + sg * ux[b] * hw], w, h)
     return mask
 
 

@@ -159,6 +159,7 @@ class QPainter:
     def drawPath(self, path): self.calls.append(("drawPath", list(path.ops)))
     def fillPath(self, path, col): self.calls.append(("fillPath", list(path.ops), col.tup()))
     def setClipPath(self, path): self.calls.append(("setClipPath", list(path.ops)))
+    def translate(self, dx, dy): self.calls.append(("translate", float(dx), float(dy)))
     def setCompositionMode(self, mode): self.calls.append(("setCompositionMode", int(mode)))
     def save(self): self.calls.append(("save",))
     def restore(self): self.calls.append(("restore",))
@@ -402,7 +403,47 @@ def capture_fill(name, mode, kind, n, sr, fps, size, view_state, sensitivity=1.0
     print(f"fill_{name}: {int(filled.sum())}/{total} frames filled, rgba {rgba[filled > 0][:1].tolist()}")
 
 
+def capture_shadow(name, mode, kind, n, sr, fps, size, view_state, frames):
+    """`_draw_shadow_path` (rt_widget.py:579-594): translate arguments, shadow pen and the order of the calls."""
+    from export.exporter import QPainterOffscreenRenderer
+    audio = _track(kind, n, sr, 2)
+    path = f"mem://shadow_{name}"
+    _AUDIO[path] = (audio, sr)
+    w, h = size
+    r = QPainterOffscreenRenderer(w, h, mode, (0.2, 0.8, 1.0), 1.0, fps, path, **view_state)
+    total = int(np.ceil(r.duration * fps))
+    out = dict(audio=audio, sample_rate=sr, fps=fps, size=np.asarray(size), mode=np.asarray(mode),
+               frames=np.asarray(frames), view_state_json=np.asarray(__import__("json").dumps(view_state)))
+    keep = set(int(f) for f in frames)
+    for i in range(total):
+        s, spec = r._read_frame(i / fps)
+        calls = r._view.render_frame_to_qimage(w, h, s, spec).calls
+        if i not in keep:
+            continue
+        out[f"f{i}_calls"] = np.asarray([c[0] for c in calls])
+        out[f"f{i}_translate"] = np.asarray([c[1:] for c in calls if c[0] == "translate"], np.float64)
+        pens = [c for c in calls if c[0] == "setPen"]
+        out[f"f{i}_pens_rgba"] = np.asarray([c[1] for c in pens], np.int64)
+        out[f"f{i}_pens_width"] = np.asarray([c[2] for c in pens], np.int64)
+        out[f"f{i}_pens_capjoin"] = np.asarray([f"{c[3]}/{c[4]}" for c in pens])
+        dps = [c for c in calls if c[0] == "drawPath"]
+        out[f"f{i}_n_drawpath"] = np.int64(len(dps))
+        out[f"f{i}_paths_equal"] = np.asarray([dps[k][1] == dps[k + 1][1] for k in range(len(dps) - 1)])
+        out[f"f{i}_path_lens"] = np.asarray([len(d[1]) for d in dps], np.int64)
+    np.savez_compressed(os.path.join(HERE, f"shadow_{name}.npz"), **out)
+    print(f"shadow_{name}: {len(out)} arrays;", list(out[f"f{frames[0]}_calls"]))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "shadow":         # adds the shadow_* fixtures only
+        _install_stand_ins()
+        sys.path.insert(0, REF)
+        capture_shadow("radial", "Spectrum - Radial", "pink", 6000, 48000, 60, (640, 368),
+                       dict(shadow_enabled=True), [0, 3])
+        capture_shadow("circular", "Waveform - Circular", "pink", 6000, 48000, 60, (640, 368),
+                       dict(shadow_enabled=True, shadow_opacity=35, shadow_blur_radius=5, shadow_distance=11,
+                            shadow_angle_deg=200, radial_fill_enabled=True, radial_fill_threshold=0.0), [0, 3])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fill":           # adds the fill_* fixtures only
         _install_stand_ins()
         sys.path.insert(0, REF)

@@ -732,3 +732,58 @@ def test_fill_decoration_raster_bit_exact(eng, mode, vs):
         assert np.array_equal(frames[f], want), (mode, f, int(np.sum(frames[f] != want)))
     assert n_filled > 0
     assert (frames == np.array(rgb, np.uint8)).all(axis=3).sum() > 1000 * n_filled
+
+
+# ------------------------------------------------------------------ shadow decoration (`_draw_shadow_path`)
+
+@pytest.mark.parametrize("mode,vs", [
+    ("Spectrum - Radial", dict(shadow_enabled=True)),
+    ("Spectrum - Radial", dict(shadow_enabled=True, shadow_opacity=80, shadow_blur_radius=3, shadow_distance=20,
+                               shadow_angle_deg=-70, edge_waviness=50, feather_audio_enabled=True,
+                               feather_audio_amount=70, radial_fill_enabled=True, radial_fill_threshold=0.0,
+                               feather_enabled=True)),
+    ("Waveform - Circular", dict(shadow_enabled=True, shadow_opacity=35, shadow_blur_radius=5, shadow_distance=11,
+                                 shadow_angle_deg=200, radial_fill_enabled=True, radial_fill_threshold=0.0)),
+])
+def test_shadow_decoration_raster_bit_exact(eng, mode, vs):
+    from aurora_amd import synth
+    from aurora_amd.engine import FillConfig, ShadowConfig
+    from aurora_amd.pipeline import FramePipeline
+    from oracle import radial_ref as RR
+    W, H, sr, fps = 640, 368, 48000, 60
+    audio = synth.pink(5000, 2, seed=77)
+    track = eng.upload_track(audio, sr, fps)
+    fc, sh = FillConfig.from_view_state(vs), ShadowConfig.from_view_state(vs)
+    radial = _radial_cfg(vs) if "Radial" in mode else None
+    pipe = FramePipeline(eng, track, mode, W, H, radial=radial, fill=fc, shadow=sh)
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    energy, pen = _np(sc.energy), _np(sc.pen_rgb)[:, :3]
+    fill_rgb = R.fill_colour_over_background(fc.rgba, fc.blend) if fc.enabled else None
+    dx, dy = sh.offset
+    rings_all = None
+    if radial is not None:
+        verts, env = eng.radial_vertices(pipe._radial_prep, an, sc, W, H, 0, an.n_frames)
+        verts, env = _np(verts), _np(env)
+        if radial.feather_enabled:
+            rings_all = _np(eng.feather_ring_vertices(pipe._radial_prep, an, sc, W, H, 0, an.n_frames))
+    else:
+        verts, env = _np(eng.wave_circular_vertices(an, sc, W, H, 0, an.n_frames, 0.0)), None
+    alphas = [max(10, 70 - 10 * k) for k in range(1, 7)]
+    for f in range(an.n_frames):
+        # the reference's painting order, layer by layer
+        want = np.empty((H, W, 3), np.uint8)
+        want[:] = np.asarray(R.BG, np.uint8)
+        if fill_rgb is not None and energy[f] >= fc.threshold:
+            want[R.unpack_mask(R.polygon_mask(verts[f], W, H), W)] = np.asarray(fill_rgb, np.uint8)
+        R.blend_solid(want, R.unpack_mask(R.stroke_mask_closed(verts[f], W, H, sh.half_width, dx, dy, True), W),
+                      (0, 0, 0), sh.alpha)
+        want[R.unpack_mask(R.stroke_mask_closed(verts[f], W, H), W)] = pen[f]
+        if env is not None:
+            R.blend_solid(want, R.unpack_mask(R.stroke_mask_closed(env[f], W, H, sh.half_width, dx, dy, False), W),
+                          (0, 0, 0), sh.alpha)
+            want[R.unpack_mask(R.polygon_mask(env[f], W, H), W)] = np.asarray(R.DISC_RGB, np.uint8)
+        if rings_all is not None:
+            for rv, a in zip(rings_all[f], alphas):
+                R.blend_solid(want, R.unpack_mask(R.polygon_mask(rv, W, H), W), R.BG, a)
+        assert np.array_equal(frames[f], want), (mode, f, int(np.sum(frames[f] != want)))

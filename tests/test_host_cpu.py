@@ -274,3 +274,52 @@ def test_new_entry_points_reject_bad_arguments_without_gpu():
     assert lib.aur_wave_circular_vertices(None, None, None, 1, None, 64, 64, None, None) != 0
     assert lib.aur_feather_ring_vertices(None, None, None, None, 1, None, None, 64, 64, None, None) != 0
     assert b"null" in lib.aur_last_error()
+
+
+def test_wide_translated_and_open_strokes_equal_brute_force():
+    """stroke_mask_closed with a half width, a translation and open ends == pixel centres inside the union of the
+    segment rectangles (square caps at open ends) and the bevel triangles, written directly from that rule."""
+    rng = np.random.default_rng(3)
+    w, h = 96, 80
+    ang = np.sort(rng.uniform(0, 2 * np.pi, 9))
+    rad = rng.uniform(12, 30, 9)
+    V = np.stack([48 + rad * np.cos(ang), 40 + rad * np.sin(ang)], axis=1)
+    py, px = np.mgrid[0:h, 0:w]
+    cx, cy = px + 0.5, py + 0.5
+    for closed in (True, False):
+        for hw, dx, dy in ((1.0, 0.0, 0.0), (3.5, 4.25, -2.5)):
+            got = R.unpack_mask(R.stroke_mask_closed(V, w, h, hw, dx, dy, closed), w)
+            P = V + np.array([dx, dy])
+            n = len(P)
+            want = np.zeros((h, w), bool)
+            nseg = n if closed else n - 1
+            U = []
+            for s in range(n):
+                d = V[(s + 1) % n] - V[s]
+                U.append(d / np.hypot(*d))
+            for s in range(nseg):
+                a, b, u = P[s], P[(s + 1) % n], U[s]
+                L = np.hypot(*(b - a))
+                along = (cx - a[0]) * u[0] + (cy - a[1]) * u[1]
+                across = -(cx - a[0]) * u[1] + (cy - a[1]) * u[0]
+                lo = -hw if (not closed and s == 0) else 0.0
+                hi = L + (hw if (not closed and s == n - 2) else 0.0)
+                want |= (along >= lo) & (along <= hi) & (np.abs(across) <= hw)
+            for v in range(n):
+                if not closed and v in (0, n - 1):
+                    continue
+                ua, ub = U[(v - 1) % n], U[v]
+                cr = ua[0] * ub[1] - ua[1] * ub[0]
+                sg = -1.0 if cr > 0 else 1.0
+                p0 = P[v]
+                p1 = p0 + sg * hw * np.array([-ua[1], ua[0]])
+                p2 = p0 + sg * hw * np.array([-ub[1], ub[0]])
+
+                def side(a, b):
+                    return (b[0] - a[0]) * (cy - a[1]) - (b[1] - a[1]) * (cx - a[0])
+
+                d0, d1, d2 = side(p0, p1), side(p1, p2), side(p2, p0)
+                want |= ((d0 >= 0) & (d1 >= 0) & (d2 >= 0)) | ((d0 <= 0) & (d1 <= 0) & (d2 <= 0))
+            diff = int(np.sum(got != want))
+            assert diff <= 2, (closed, hw, diff)      # pixel centres within rounding of an outline edge
+            assert got.sum() > 200

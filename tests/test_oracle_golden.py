@@ -262,3 +262,35 @@ def test_fill_colour_composition_rules():
     assert R.fill_colour_over_background((255, 255, 255, 128), "add") == (141, 141, 146)
     assert R.fill_colour_over_background((255, 255, 255, 255), "multiply") == (13, 13, 18)
     assert R.fill_colour_over_background((0, 0, 0, 0), "normal") == (13, 13, 18)
+
+
+@pytest.mark.parametrize("fixture", ["shadow_radial", "shadow_circular"])
+def test_shadow_decoration_matches_reference_calls(fixture):
+    """`_draw_shadow_path` (rt_widget.py:579-594): translate arguments, pen (colour, alpha, width, cap/join), the order
+    of the calls and which paths are stroked, against the host's ShadowConfig."""
+    import json
+    from aurora_amd.engine import ShadowConfig
+    g = load_golden(fixture)
+    vs = json.loads(str(g["view_state_json"]))
+    sh = ShadowConfig.from_view_state(vs)
+    assert sh.active
+    radial = "Radial" in str(g["mode"])
+    for f in g["frames"]:
+        k = f"f{int(f)}"
+        tr = g[k + "_translate"]
+        assert tr.shape == ((2, 2) if radial else (1, 2))
+        assert all(tuple(t) == sh.offset for t in tr)
+        pens = g[k + "_pens_rgba"]
+        assert [tuple(p) for p in pens[1:]] == [(0, 0, 0, sh.alpha)] * (len(pens) - 1)
+        assert list(g[k + "_pens_width"][1:]) == [int(2 * sh.half_width)] * (len(pens) - 1)
+        assert set(g[k + "_pens_capjoin"]) == {"SquareCap/BevelJoin"}
+        calls = list(g[k + "_calls"])
+        if radial:   # shadow of the path, stroke of the same path, shadow of the (open, 361-op) envelope path, disc
+            assert calls == ['fillRect', 'setPen', 'save', 'translate', 'setPen', 'drawPath', 'restore', 'drawPath',
+                             'save', 'translate', 'setPen', 'drawPath', 'restore', 'save', 'setRenderHint',
+                             'setClipPath', 'fillPath', 'restore', 'end']
+            assert list(g[k + "_paths_equal"]) == [True, False] and list(g[k + "_path_lens"]) == [722, 722, 361]
+        else:        # fill, shadow, stroke of one closed 1024-vertex path
+            assert calls == ['fillRect', 'setPen', 'save', 'fillPath', 'restore', 'save', 'translate', 'setPen',
+                             'drawPath', 'restore', 'drawPath', 'end']
+            assert list(g[k + "_paths_equal"]) == [True] and list(g[k + "_path_lens"]) == [1025, 1025]

@@ -289,7 +289,7 @@ class HipExportEngine:
         self.device = torch.device("cuda", self.device_index)
         self.ctx = _lib.Context(self.device_index)
         self.lib = self.ctx.lib
-        self._col2samp = {}
+        self._tables = {}
         self._work = None
 
     # ------------------------------------------------------------------ plumbing
@@ -376,9 +376,9 @@ class HipExportEngine:
 
     # ------------------------------------------------------------------ raster
     def col2samp(self, W: int):
-        if W not in self._col2samp:
-            self._col2samp[W] = self.torch.from_numpy(waveform_col2samp(W)).to(self.device)
-        return self._col2samp[W]
+        if W not in self._tables:
+            self._tables[W] = self.torch.from_numpy(waveform_col2samp(W)).to(self.device)
+        return self._tables[W]
 
     def spans(self, kind: str, an: Analysis, sc: Scan, W: int, H: int, first: int = 0, count: int | None = None,
               out=None):
@@ -475,10 +475,10 @@ class HipExportEngine:
             _lib.check(self.lib.aur_radial_ema(h, _ptr(vals1), F, L1, float(cfg.radial_temporal_alpha), int(has),
                                                _ptr(st_t), st), "aur_radial_ema")
         key = ("radial", cfg.L2, cfg.radial_rotation_deg)
-        if key not in self._col2samp:
-            self._col2samp[key] = (torch.from_numpy(angle_table(cfg.L2, cfg.radial_rotation_deg)).to(self.device),
+        if key not in self._tables:
+            self._tables[key] = (torch.from_numpy(angle_table(cfg.L2, cfg.radial_rotation_deg)).to(self.device),
                                    torch.from_numpy(angle_table(360, cfg.radial_rotation_deg)).to(self.device))
-        cs, cs360 = self._col2samp[key]
+        cs, cs360 = self._tables[key]
         return RadialPrep(cfg, vals1, st_t, cs, cs360, {})
 
     def carried_radial_state(self, track: Track, frame_begin: int, cfg: RadialConfig, chunk: int = 16384):
@@ -666,12 +666,12 @@ class HipExportEngine:
         if an.samples is None:
             raise ValueError("Waveform - Circular needs analyze(..., want_samples=True)")
         key = ("wavecirc", float(rotation_deg))
-        if key not in self._col2samp:
-            self._col2samp[key] = self.torch.from_numpy(wave_circular_angle_table(rotation_deg)).to(self.device)
+        if key not in self._tables:
+            self._tables[key] = self.torch.from_numpy(wave_circular_angle_table(rotation_deg)).to(self.device)
         verts = self.empty((count, BLOCK, 2), self.torch.float64)
         _lib.check(self.lib.aur_wave_circular_vertices(
             self.ctx.handle, _ptr(an.samples[first:first + count]), _ptr(sc.energy[first:first + count]), count,
-            _ptr(self._col2samp[key]), W, H, _ptr(verts), self.stream()), "aur_wave_circular_vertices")
+            _ptr(self._tables[key]), W, H, _ptr(verts), self.stream()), "aur_wave_circular_vertices")
         return verts
 
     def wave_circular_planes(self, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int,
@@ -684,9 +684,9 @@ class HipExportEngine:
         _lib.check(self.lib.aur_mask_stroke_closed(self.ctx.handle, _ptr(verts), BLOCK, count, W, H, _ptr(stroke),
                                                    self.stream()), "aur_mask_stroke_closed")
         key = ("nodisc", W, H)
-        if key not in self._col2samp:
-            self._col2samp[key] = torch.zeros((1, H, W32), dtype=torch.int32, device=self.device)
-        return stroke, self._col2samp[key], True
+        if key not in self._tables:
+            self._tables[key] = torch.zeros((1, H, W32), dtype=torch.int32, device=self.device)
+        return stroke, self._tables[key], True
 
     def render_wave_circular(self, an: Analysis, sc: Scan, W: int, H: int, first: int = 0, count: int | None = None,
                              rotation_deg: float = 0.0, out=None, planes_out=None, fill: FillConfig | None = None,

@@ -313,6 +313,24 @@ __global__ __launch_bounds__(256) void wave_circular_vertices_kernel(const float
     dst[1] = cy + cs[2 * i + 1] * r;                                        // :890
 }
 
+// ---- "Waveform - Linear" as a path (only needed when its shadow is drawn) ---------------------------------------------
+// rt_widget.py:904-913: vertex x is (x, float(mid - samples[i] * amp)), i = col2samp[x]; the product and the difference
+// are float32 (np.float32 with Python floats, NEP 50), exactly as in spans_waveform_kernel (raster.hip).
+__global__ __launch_bounds__(256) void wave_linear_vertices_kernel(const float* __restrict__ samples,
+                                                                   const int* __restrict__ col2samp,
+                                                                   const double* __restrict__ energy, int W, int H,
+                                                                   double* __restrict__ verts) {
+    const int f = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const double amp = 0.45 * ((double)H / 2.0) * (0.5 + energy[f]);
+    const float amp32 = (float)amp;
+    const float mid32 = (float)((double)H / 2.0);
+    double* dst = verts + ((long)f * W + x) * 2;
+    dst[0] = (double)x;
+    dst[1] = (double)(mid32 - samples[(long)f * AUR_BLOCK + col2samp[x]] * amp32);
+}
+
 // ---- bit planes -------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ void or_span(uint32_t* row, int c0, int c1, int W) {
@@ -383,13 +401,17 @@ __device__ __forceinline__ bool seg_dir(const double* V, int n, int s, double& u
 // tx = ty = 0 reproduce the untranslated width-2 stroke bit for bit (x + 0 and n * 1 are exact).
 __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* __restrict__ verts, int nv, int W, int H,
                                                                  int W32, double hw, double tx, double ty,
-                                                                 int closed, uint32_t* __restrict__ planes) {
+                                                                 int closed, int round_join,
+                                                                 uint32_t* __restrict__ planes) {
     // closed == 0: open polyline (the envelope path of `_draw_center_image_and_mask` has no closeSubpath): no segment
     // from the last vertex to the first, no join at either end, SquareCap = the end segments extended by hw.
     const int f = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= 2 * nv) return;
-    if (!closed && (t == nv - 1 || t == nv || t == 2 * nv - 1)) return;
+    // round_join != 0 (RoundCap / RoundJoin pen): plain segment rectangles and a disc of radius hw at every vertex,
+    // i.e. every pixel centre within hw of the polyline.
+    if (!closed && t == nv - 1) return;
+    if (!closed && !round_join && (t == nv || t == 2 * nv - 1)) return;
     const double* V = verts + (long)f * nv * 2;
     uint32_t* plane = planes + (long)f * H * W32;
     double px[4], py[4];
@@ -398,11 +420,11 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
         if (!seg_dir(V, nv, t, ux, uy)) return;
         const int t1 = (t + 1 == nv) ? 0 : t + 1;
         double ax = V[2 * t] + tx, ay = V[2 * t + 1] + ty, bx = V[2 * t1] + tx, by = V[2 * t1 + 1] + ty;
-        if (!closed && t == 0) {
+        if (!closed && !round_join && t == 0) {
             ax = ax - ux * hw;
             ay = ay - uy * hw;
         }
-        if (!closed && t == nv - 2) {
+        if (!closed && !round_join && t == nv - 2) {
             bx = bx + ux * hw;
             by = by + uy * hw;
         }
@@ -414,6 +436,23 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
         raster_convex(plane, W32, px, py, 4, W, H);
     } else {
         const int v = t - nv;
+        if (round_join) {
+            const double vx = V[2 * v] + tx, vy = V[2 * v + 1] + ty;
+            if (!(vx == vx) || !(vy == vy)) return;
+            const double yl = fmin(fmax(vy - hw, -kBig), kBig), yh = fmin(fmax(vy + hw, -kBig), kBig);
+            long r0 = (long)ceil(yl - 0.5), r1 = (long)floor(yh - 0.5) + 1;
+            if (r0 < 0) r0 = 0;
+            if (r1 > H) r1 = H;
+            for (long r = r0; r < r1; ++r) {
+                const double dyc = ((double)r + 0.5) - vy;
+                const double c2 = hw * hw - dyc * dyc;
+                if (c2 < 0.0) continue;
+                const double c = sqrt(c2);
+                const double xl = fmin(fmax(vx - c, -kBig), kBig), xh = fmin(fmax(vx + c, -kBig), kBig);
+                or_span(plane + r * W32, (int)ceil(xl - 0.5), (int)floor(xh - 0.5) + 1, W);
+            }
+            return;
+        }
         const int a = (v == 0) ? nv - 1 : v - 1;
         double uxa, uya, uxb, uyb;
         if (!seg_dir(V, nv, a, uxa, uya) || !seg_dir(V, nv, v, uxb, uyb)) return;
@@ -814,6 +853,22 @@ __global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __res
     }
 }
 
+extern "C" int aur_wave_linear_vertices(aur_ctx* ctx, const float* d_samples, const int32_t* d_col2samp,
+                                        const double* d_energy, int n_frames, int W, int H, double* d_verts,
+                                        void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_wave_linear_vertices: n_frames %d outside [0, 65535]", n_frames);
+    AUR_REQUIRE(W >= 16 && W <= kMaxL + 1 && H >= 16, "aur_wave_linear_vertices: frame %dx%d unsupported (W <= %d)", W, H,
+                kMaxL + 1);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_samples && d_col2samp && d_energy && d_verts, "aur_wave_linear_vertices: null device pointer");
+    hipLaunchKernelGGL(wave_linear_vertices_kernel, dim3((W + 255) / 256, n_frames), dim3(256), 0, (hipStream_t)stream,
+                       d_samples, d_col2samp, d_energy, W, H, d_verts);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
 extern "C" int aur_wave_circular_vertices(aur_ctx* ctx, const float* d_samples, const double* d_energy, int n_frames,
                                           const double* d_cos_sin, int W, int H, double* d_verts, void* stream) {
     int rc = aur_use_device(ctx);
@@ -892,12 +947,12 @@ static int check_plane_args(const char* who, int n_frames, int nv, int W, int H)
 
 extern "C" int aur_mask_stroke_closed(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
                                       uint32_t* d_plane, void* stream) {
-    return aur_mask_stroke_path(ctx, d_verts, n_vertices, n_frames, W, H, 1.0, 0.0, 0.0, 1, d_plane, stream);
+    return aur_mask_stroke_path(ctx, d_verts, n_vertices, n_frames, W, H, 1.0, 0.0, 0.0, 1, 0, d_plane, stream);
 }
 
 extern "C" int aur_mask_stroke_path(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
-                                    double half_width, double dx, double dy, int closed, uint32_t* d_plane,
-                                    void* stream) {
+                                    double half_width, double dx, double dy, int closed, int round_join,
+                                    uint32_t* d_plane, void* stream) {
     int rc = aur_use_device(ctx);
     if (rc) return rc;
     if ((rc = check_plane_args("aur_mask_stroke_closed", n_frames, n_vertices, W, H))) return rc;
@@ -911,7 +966,7 @@ extern "C" int aur_mask_stroke_path(aur_ctx* ctx, const double* d_verts, int n_v
     hipStream_t st = (hipStream_t)stream;
     AUR_CHECK_HIP(hipMemsetAsync(d_plane, 0, (size_t)n_frames * H * W32 * 4, st));
     hipLaunchKernelGGL(mask_stroke_closed_kernel, dim3((2 * n_vertices + 255) / 256, n_frames), dim3(256), 0, st,
-                       d_verts, n_vertices, W, H, W32, half_width, dx, dy, closed ? 1 : 0, d_plane);
+                       d_verts, n_vertices, W, H, W32, half_width, dx, dy, closed ? 1 : 0, round_join ? 1 : 0, d_plane);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -162,7 +162,8 @@ class FillConfig:
 @dataclass
 class ShadowConfig:
     """`_draw_shadow_path` (rt_widget.py:579-594) as an export configures it (export/exporter.py:212-223; widget
-    defaults rt_widget.py:80-85).  Closed paths only ("Spectrum - Radial", "Waveform - Circular")."""
+    defaults rt_widget.py:80-85): the closed paths ("Spectrum - Radial", "Waveform - Circular") and the linear waveform's
+    own variant."""
     enabled: bool = False
     opacity: float = 0.6
     blur: int = 16
@@ -202,6 +203,17 @@ class ShadowConfig:
     @property
     def half_width(self):
         return max(2, self.blur) / 2.0                                                   # pen.setWidth(max(2, blur)), :591
+
+    # "Waveform - Linear" draws its own shadow (rt_widget.py:915-928): RoundCap / RoundJoin pen of width
+    # max(2, min(10, blur)), translated by (distance, distance) whatever the angle
+    @property
+    def linear_pen_width(self):
+        return max(2, min(10, self.blur))                                                # :918
+
+    @property
+    def linear_offset(self):
+        d = float(self.distance)                                                         # :924-925
+        return d, d
 
 
 def angle_table(n: int, rotation_deg: float) -> np.ndarray:
@@ -539,7 +551,8 @@ class HipExportEngine:
                                               _ptr(enable), count, W, H, st), "aur_plane_exclude")
         return self.blend_planes(plane, bytes(fill.colour_over_background()) + b"\xff", frames)
 
-    def apply_shadow(self, shadow: ShadowConfig, verts, closed: bool, excl_a, excl_b, excl_b_static, frames):
+    def apply_shadow(self, shadow: ShadowConfig, verts, closed: bool, excl_a, excl_b, excl_b_static, frames,
+                     round_join: bool = False, half_width=None, offset=None):
         """`_draw_shadow_path` of ``verts`` float64 [count, n, 2]: translated wide stroke in QColor(0, 0, 0, alpha),
         source-over on the frame wherever the planes ``excl_a`` / ``excl_b`` (what the reference paints afterwards
         with opaque colours) have no bit (in place)."""
@@ -548,9 +561,10 @@ class HipExportEngine:
         W32 = (W + 31) // 32
         h, st = self.ctx.handle, self.stream()
         plane = self.empty((count, 1, H, W32), torch.int32)
-        dx, dy = shadow.offset
+        dx, dy = shadow.offset if offset is None else offset
         _lib.check(self.lib.aur_mask_stroke_path(h, _ptr(verts), int(verts.shape[1]), count, W, H,
-                                                 float(shadow.half_width), float(dx), float(dy), int(bool(closed)),
+                                                 float(half_width if half_width is not None else shadow.half_width),
+                                                 float(dx), float(dy), int(bool(closed)), int(bool(round_join)),
                                                  _ptr(plane), st), "aur_mask_stroke_path")
         _lib.check(self.lib.aur_plane_exclude(h, _ptr(plane), _ptr(excl_a), _ptr(excl_b), int(bool(excl_b_static)),
                                               None, count, W, H, st), "aur_plane_exclude")
@@ -657,6 +671,37 @@ class HipExportEngine:
             self.apply_shadow(shadow, env, False, None, planes[1], planes[2], out)                # :1053-1054
         if prep.cfg.feather_enabled:
             self.feather_blend(prep, an, sc, W, H, first, count, out)
+        return out
+
+    # ------------------------------------------------------------------ Waveform - Linear with its shadow
+    def wave_linear_vertices(self, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int):
+        """Polyline float64 [count, W, 2] of "Waveform - Linear" (rt_widget.py:904-913)."""
+        if an.samples is None:
+            raise ValueError("Waveform - Linear needs analyze(..., want_samples=True)")
+        verts = self.empty((count, W, 2), self.torch.float64)
+        _lib.check(self.lib.aur_wave_linear_vertices(
+            self.ctx.handle, _ptr(an.samples[first:first + count]), _ptr(self.col2samp(W)),
+            _ptr(sc.energy[first:first + count]), count, W, H, _ptr(verts), self.stream()), "aur_wave_linear_vertices")
+        return verts
+
+    def render_wave_linear_shadow(self, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int,
+                                  shadow: ShadowConfig, out=None):
+        """"Waveform - Linear" with its shadow (rt_widget.py:915-932): the shadow is the polyline translated by
+        (distance, distance), stroked with a RoundCap / RoundJoin pen of width max(2, min(10, blur)) in
+        QColor(0, 0, 0, alpha); the polyline itself is stroked through a bit plane here (same coverage rule as the
+        column spans of the plain mode: pixel centre inside the width-2 SquareCap / BevelJoin outline)."""
+        torch = self.torch
+        W32 = (W + 31) // 32
+        verts = self.wave_linear_vertices(an, sc, W, H, first, count)
+        stroke = self.empty((count, H, W32), torch.int32)
+        _lib.check(self.lib.aur_mask_stroke_path(self.ctx.handle, _ptr(verts), W, count, W, H, 1.0, 0.0, 0.0, 0, 0,
+                                                 _ptr(stroke), self.stream()), "aur_mask_stroke_path")
+        key = ("nodisc", W, H)
+        if key not in self._tables:
+            self._tables[key] = torch.zeros((1, H, W32), dtype=torch.int32, device=self.device)
+        out = self.fill_planes((stroke, self._tables[key], True), sc.pen_rgb[first:first + count], W, H, out)
+        self.apply_shadow(shadow, verts, False, stroke, None, True, out, round_join=True,
+                          half_width=shadow.linear_pen_width / 2.0, offset=shadow.linear_offset)
         return out
 
     # ------------------------------------------------------------------ Waveform - Circular

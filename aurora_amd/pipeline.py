@@ -99,10 +99,9 @@ class FramePipeline:
         self.planes = self.kind in PLANE_KINDS
         self.fill = fill if (fill is not None and fill.enabled and self.planes) else None    # `_apply_fill`: closed paths only
         # the reference draws no shadow for the bar spectrum or the particles; the linear waveform has its own
-        # RoundCap / RoundJoin variant (rt_widget.py:915-930), which is not built
-        if shadow is not None and shadow.active and self.kind == "waveform_linear":
-            raise NotImplementedError("shadow of 'Waveform - Linear' is not implemented on the HIP path")
-        self.shadow = shadow if (shadow is not None and shadow.active and self.planes) else None
+        # RoundCap / RoundJoin variant (rt_widget.py:915-930)
+        self.shadow = shadow if (shadow is not None and shadow.active and
+                                 (self.planes or self.kind == "waveform_linear")) else None
         self._analysed = None
         self._radial_prep = None
 
@@ -129,6 +128,9 @@ class FramePipeline:
         if self.radial is not None:
             return self.eng.render_radial(self._radial_prep, an, sc, self.W, self.H, first, count, out=out,
                                           planes_out=scratch, fill=self.fill, shadow=self.shadow)
+        if self.kind == "waveform_linear" and self.shadow is not None:
+            n = an.n_frames - first if count is None else count
+            return self.eng.render_wave_linear_shadow(an, sc, self.W, self.H, first, n, self.shadow, out=out)
         if self.kind == "waveform_circular":
             return self.eng.render_wave_circular(an, sc, self.W, self.H, first, count, self.rotation_deg, out=out,
                                                  planes_out=scratch, fill=self.fill, shadow=self.shadow)

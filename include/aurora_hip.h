@@ -255,9 +255,18 @@ int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_
  * `_draw_shadow_path` (rt_widget.py:579-594) strokes a path with a QPen of width max(2, shadow_blur), default
  * SquareCap / BevelJoin, after `p.translate(dist cos(angle), dist sin(angle))`; the radial / circular paths end with
  * closeSubpath, the envelope path of the centre disc does not (closed = 0: no closing segment, no join at the ends,
- * square caps).  half_width = 1, dx = dy = 0, closed = 1 is aur_mask_stroke_closed bit for bit. */
+ * square caps).  half_width = 1, dx = dy = 0, closed = 1 is aur_mask_stroke_closed bit for bit.
+ * round_join != 0: RoundCap / RoundJoin pen = every pixel centre within half_width of the polyline (segment rectangles
+ * and a disc at every vertex): the shadow of "Waveform - Linear" (rt_widget.py:915-928). */
 int aur_mask_stroke_path(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
-                         double half_width, double dx, double dy, int closed, uint32_t* d_plane, void* stream);
+                         double half_width, double dx, double dy, int closed, int round_join, uint32_t* d_plane,
+                         void* stream);
+
+/* The polyline of "Waveform - Linear" as vertices (rt_widget.py:904-913): d_verts float64 [n_frames, W, 2] =
+ * (x, float(mid - samples[col2samp[x]] * amp)), the values aur_spans_waveform_linear rasterises.  Needed when the
+ * shadow of the mode is drawn (the path is then stroked through bit planes).  W <= 4097. */
+int aur_wave_linear_vertices(aur_ctx* ctx, const float* d_samples, const int32_t* d_col2samp, const double* d_energy,
+                             int n_frames, int W, int H, double* d_verts, void* stream);
 
 /* d_plane &= ~(d_excl_a | d_excl_b) per frame (either may be NULL; excl_b_static != 0: one plane for all frames), and the
  * plane of frame f is cleared when d_enable != NULL and d_enable[f] == 0.  Used for `_apply_fill` (rt_widget.py:856-864,

@@ -370,9 +370,10 @@ def _raster_convex(mask, px, py, w, h):
         _or_span(mask, r, math.ceil(xmin - 0.5), math.floor(xmax - 0.5) + 1, w)
 
 
-def stroke_mask_closed(verts, w, h, half_width=1.0, dx=0.0, dy=0.0, closed=True):
+def stroke_mask_closed(verts, w, h, half_width=1.0, dx=0.0, dy=0.0, closed=True, round_join=False):
     """Bit plane of a BevelJoin stroke (pen width 2 * half_width) of the polygon through ``verts`` float64[n, 2]
-    translated by (dx, dy); closed=False: open polyline with SquareCap ends (`_draw_shadow_path` of the envelope)."""
+    translated by (dx, dy); closed=False: open polyline with SquareCap ends (`_draw_shadow_path` of the envelope);
+    round_join=True: RoundCap / RoundJoin pen = plain segment rectangles + a disc of radius half_width per vertex."""
     import math as _m
     V = np.asarray(verts, dtype=np.float64)
     n = V.shape[0]
@@ -392,13 +393,27 @@ def stroke_mask_closed(verts, w, h, half_width=1.0, dx=0.0, dy=0.0, closed=True)
             continue
         ax, ay = V[s][0] + tx, V[s][1] + ty
         bx, by = V[(s + 1) % n][0] + tx, V[(s + 1) % n][1] + ty
-        if not closed and s == 0:            # SquareCap: the end segments are extended by the half width
+        if not closed and not round_join and s == 0:     # SquareCap: the end segments are extended by the half width
             ax, ay = ax - ux[s] * hw, ay - uy[s] * hw
-        if not closed and s == n - 2:
+        if not closed and not round_join and s == n - 2:
             bx, by = bx + ux[s] * hw, by + uy[s] * hw
         nx, ny = -uy[s] * hw, ux[s] * hw
         _raster_convex(mask, [ax + nx, bx + nx, bx - nx, ax - nx], [ay + ny, by + ny, by - ny, ay - ny], w, h)
-    for v in range(n):                       # bevel at V[v] between segments v-1 and v
+    for v in range(n):                       # bevel at V[v] between segments v-1 and v (or a disc: round joins and caps)
+        if round_join:
+            vx, vy = V[v][0] + tx, V[v][1] + ty
+            yl = min(max(vy - hw, -_BIG), _BIG)
+            yh = min(max(vy + hw, -_BIG), _BIG)
+            for r in range(max(0, int(math.ceil(yl - 0.5))), min(h, int(math.floor(yh - 0.5)) + 1)):
+                dyc = (r + 0.5) - vy
+                c2 = hw * hw - dyc * dyc
+                if c2 < 0.0:
+                    continue
+                c = _m.sqrt(c2)
+                xl = min(max(vx - c, -_BIG), _BIG)
+                xh = min(max(vx + c, -_BIG), _BIG)
+                _or_span(mask, r, math.ceil(xl - 0.5), math.floor(xh - 0.5) + 1, w)
+            continue
         if not closed and (v == 0 or v == n - 1):
             continue
         a, b = (v - 1) % n, v

@@ -444,6 +444,13 @@ def main():
                        dict(shadow_enabled=True, shadow_opacity=35, shadow_blur_radius=5, shadow_distance=11,
                             shadow_angle_deg=200, radial_fill_enabled=True, radial_fill_threshold=0.0), [0, 3])
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "shadow_linear":  # adds the shadow_linear fixture only
+        _install_stand_ins()
+        sys.path.insert(0, REF)
+        capture_shadow("linear", "Waveform - Linear", "pink", 6000, 48000, 60, (640, 368),
+                       dict(shadow_enabled=True, shadow_opacity=50, shadow_blur_radius=6, shadow_distance=9,
+                            shadow_angle_deg=120), [0, 3])
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "fill":           # adds the fill_* fixtures only
         _install_stand_ins()
         sys.path.insert(0, REF)

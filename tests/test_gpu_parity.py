@@ -357,6 +357,16 @@ def test_worker_end_to_end_raw_stream(eng, tmp_path, capsys):
     track = eng.upload_track(audio, sr, fps)
     want = _np(FramePipeline(eng, track, "Spectrum - Linear", W, H).render_device()).tobytes()
     assert raw.read_bytes() == want
+    # the linear waveform with its shadow keys, through the same worker
+    from aurora_amd.engine import ShadowConfig
+    vs = {"hip_device": 0, "shadow_enabled": True, "shadow_distance": 5, "shadow_blur_radius": 7}
+    cfg.update(mode="Waveform - Linear", view_state=vs)
+    cfgp.write_text(json.dumps(cfg))
+    assert worker.main(["worker.py", str(cfgp)]) == 0
+    capsys.readouterr()
+    want = _np(FramePipeline(eng, track, "Waveform - Linear", W, H,
+                             shadow=ShadowConfig.from_view_state(vs)).render_device()).tobytes()
+    assert raw.read_bytes() == want
     # unsupported decoration -> exit 1 with an error message, as the reference reports export failures (worker.py:77-79)
     cfg["view_state"] = {"hip_device": 0, "glow_enabled": True}
     cfgp.write_text(json.dumps(cfg))
@@ -787,3 +797,57 @@ def test_shadow_decoration_raster_bit_exact(eng, mode, vs):
             for rv, a in zip(rings_all[f], alphas):
                 R.blend_solid(want, R.unpack_mask(R.polygon_mask(rv, W, H), W), R.BG, a)
         assert np.array_equal(frames[f], want), (mode, f, int(np.sum(frames[f] != want)))
+
+
+# ------------------------------------------------------------------ shadow of "Waveform - Linear" (rt_widget.py:915-930)
+
+@pytest.mark.parametrize("vs", [
+    dict(shadow_enabled=True),
+    dict(shadow_enabled=True, shadow_opacity=90, shadow_blur_radius=3, shadow_distance=25),
+    dict(shadow_enabled=True, shadow_opacity=40, shadow_blur_radius=0, shadow_distance=0),
+])
+@pytest.mark.parametrize("size", [(640, 368), (252, 130)])
+def test_wave_linear_shadow_raster_bit_exact(eng, vs, size):
+    from aurora_amd import synth
+    from aurora_amd.engine import ShadowConfig
+    from aurora_amd.pipeline import FramePipeline
+    W, H = size
+    sr, fps = 48000, 60
+    audio = synth.pink(5000, 2, seed=78) * 1.6
+    track = eng.upload_track(audio, sr, fps)
+    sh = ShadowConfig.from_view_state(vs)
+    pipe = FramePipeline(eng, track, "Waveform - Linear", W, H, shadow=sh)
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    plain = _np(FramePipeline(eng, track, "Waveform - Linear", W, H).render_device())
+    samples, energy, pen = _np(an.samples), _np(sc.energy), _np(sc.pen_rgb)[:, :3]
+    penw, (d, _) = sh.linear_pen_width, sh.linear_offset     # pinned to the reference's calls by shadow_linear.npz
+    bg = np.asarray(R.BG, np.uint8)
+    for f in range(an.n_frames):
+        Y = R.drawlist_waveform_linear(samples[f], float(energy[f]), W, H)
+        verts = np.stack([np.arange(W, dtype=np.float64), Y], axis=1)
+        want = np.empty((H, W, 3), np.uint8)
+        want[:] = bg
+        R.blend_solid(want, R.unpack_mask(R.stroke_mask_closed(verts, W, H, penw / 2.0, d, d, False, round_join=True), W),
+                      (0, 0, 0), sh.alpha)
+        # the polyline itself: the column-span rule of the plain mode (the HIP path strokes it through a bit plane here)
+        line = (plain[f] != bg).any(axis=2)
+        assert np.array_equal(plain[f], R.rasterize_spans(R.spans_polyline(Y, W, H), pen[f], W, H))
+        want[line] = pen[f]
+        assert np.array_equal(frames[f], want), (f, int(np.sum(frames[f] != want)))
+    assert (frames != plain).any()
+
+
+def test_wave_linear_vertices_match_drawlist(eng):
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    W, H = 333, 200
+    track = eng.upload_track(synth.pink(3000, 2, seed=5), 48000, 60)
+    pipe = FramePipeline(eng, track, "Waveform - Linear", W, H)
+    an, sc = pipe.analyse()
+    got = _np(eng.wave_linear_vertices(an, sc, W, H, 0, an.n_frames))
+    samples, energy = _np(an.samples), _np(sc.energy)
+    for f in range(an.n_frames):
+        Y = R.drawlist_waveform_linear(samples[f], float(energy[f]), W, H)
+        assert np.array_equal(got[f, :, 0], np.arange(W, dtype=np.float64))
+        assert np.array_equal(got[f, :, 1], Y)

@@ -323,3 +323,26 @@ def test_wide_translated_and_open_strokes_equal_brute_force():
             diff = int(np.sum(got != want))
             assert diff <= 2, (closed, hw, diff)      # pixel centres within rounding of an outline edge
             assert got.sum() > 200
+
+
+def test_round_stroke_equals_distance_to_polyline():
+    """round_join=True (RoundCap / RoundJoin pen, the shadow of "Waveform - Linear", rt_widget.py:918-927) == every pixel
+    centre within the half width of the translated polyline; pixels closer than 1e-9 to the boundary are not compared."""
+    rng = np.random.default_rng(11)
+    w, h = 96, 64
+    xs = np.arange(0, w, 4, dtype=np.float64)
+    V = np.stack([xs, 32 + rng.uniform(-20, 20, len(xs))], axis=1)
+    py, px = np.mgrid[0:h, 0:w]
+    cx, cy = px + 0.5, py + 0.5
+    for hw, d in ((1.0, 0.0), (2.5, 3.0), (5.0, 8.0)):
+        got = R.unpack_mask(R.stroke_mask_closed(V, w, h, hw, d, d, False, round_join=True), w)
+        P = V + d
+        dist = np.full((h, w), np.inf)
+        for s in range(len(P) - 1):
+            a, b = P[s], P[s + 1]
+            ab = b - a
+            t = np.clip(((cx - a[0]) * ab[0] + (cy - a[1]) * ab[1]) / (ab @ ab), 0.0, 1.0)
+            dist = np.minimum(dist, np.hypot(cx - (a[0] + t * ab[0]), cy - (a[1] + t * ab[1])))
+        sure = np.abs(dist - hw) > 1e-9
+        assert np.array_equal(got[sure], (dist <= hw)[sure])
+        assert got.any() and not got.all()

@@ -294,3 +294,26 @@ def test_shadow_decoration_matches_reference_calls(fixture):
             assert calls == ['fillRect', 'setPen', 'save', 'fillPath', 'restore', 'save', 'translate', 'setPen',
                              'drawPath', 'restore', 'drawPath', 'end']
             assert list(g[k + "_paths_equal"]) == [True] and list(g[k + "_path_lens"]) == [1025, 1025]
+
+
+def test_linear_waveform_shadow_matches_reference_calls():
+    """The shadow of "Waveform - Linear" (rt_widget.py:915-930): one translate by (distance, distance) whatever the
+    angle, a RoundCap / RoundJoin pen of width max(2, min(10, blur)) in QColor(0, 0, 0, alpha), the same open W-vertex
+    path stroked twice (shadow, then the mode's pen)."""
+    import json
+    from aurora_amd.engine import ShadowConfig
+    g = load_golden("shadow_linear")
+    vs = json.loads(str(g["view_state_json"]))
+    sh = ShadowConfig.from_view_state(vs)
+    assert sh.active and sh.angle_deg == 120
+    W = int(g["size"][0])
+    for f in g["frames"]:
+        k = f"f{int(f)}"
+        assert [tuple(t) for t in g[k + "_translate"]] == [sh.linear_offset]
+        pens = g[k + "_pens_rgba"]
+        assert [tuple(p) for p in pens] == [tuple(pens[0]), (0, 0, 0, sh.alpha), tuple(pens[0])]
+        assert list(g[k + "_pens_width"]) == [2, sh.linear_pen_width, 2]
+        assert list(g[k + "_pens_capjoin"]) == ["SquareCap/BevelJoin", "RoundCap/RoundJoin", "SquareCap/BevelJoin"]
+        assert list(g[k + "_calls"]) == ['fillRect', 'setPen', 'save', 'translate', 'setPen', 'drawPath', 'restore',
+                                         'setPen', 'drawPath', 'end']
+        assert list(g[k + "_paths_equal"]) == [True] and list(g[k + "_path_lens"]) == [W, W]

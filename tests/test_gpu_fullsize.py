@@ -150,3 +150,46 @@ def test_full_track_render_checksums_and_samples(eng, track4min, mode, size):
         assert np.array_equal(got, want), (mode, f)
         cols = {tuple(c) for c in np.unique(got.reshape(-1, 3), axis=0)}
         assert cols <= palette and tuple(R.BG) in cols
+
+
+def test_full_track_linear_waveform_shadow_properties(eng, track4min):
+    """"Waveform - Linear" 4K with its shadow over the whole track: the shadowed render differs from the plain one only
+    on background pixels, which all take the one blended shadow colour -- so the polyline stroked through a bit plane
+    (shadow path) covers exactly the pixels of the column-span rasteriser (plain path) in every frame -- and every frame
+    has shadow pixels below/right of the line."""
+    import torch
+    from aurora_amd.engine import ShadowConfig
+    track, an, sc = track4min
+    W, H = 3840, 2160
+    F = track.total_frames
+    sh = ShadowConfig(enabled=True, opacity=0.6, blur=16, distance=8)
+    one = np.empty((1, 1, 3), np.uint8)
+    one[:] = np.asarray(R.BG, np.uint8)
+    R.blend_solid(one, np.ones((1, 1), bool), (0, 0, 0), sh.alpha)
+    shade = torch.tensor(one[0, 0].tolist(), dtype=torch.uint8, device=eng.device)
+    bg = torch.tensor(list(R.BG), dtype=torch.uint8, device=eng.device)
+    assert not torch.equal(shade, bg)
+    done, batch = 0, 48
+    while done < F:
+        n = min(batch, F - done)
+        plain = eng.render("Waveform - Linear", an, sc, W, H, done, n)
+        shad = eng.render_wave_linear_shadow(an, sc, W, H, done, n, sh)
+        diff = (plain != shad).any(dim=-1)
+        assert bool((plain[diff] == bg).all()) and bool((shad[diff] == shade).all()), done
+        # no shadow colour anywhere else, and some of it in every frame
+        assert bool(((shad == shade).all(dim=-1) == diff).all()), done
+        assert bool(diff.view(n, -1).any(dim=1).all()), done
+        done += n
+    # one frame against the oracle, layer by layer
+    f = F // 3
+    got = _np(eng.render_wave_linear_shadow(an, sc, W, H, f, 1, sh))[0]
+    Y = R.drawlist_waveform_linear(_np(an.samples[f]), float(_np(sc.energy)[f]), W, H)
+    verts = np.stack([np.arange(W, dtype=np.float64), Y], axis=1)
+    want = np.empty((H, W, 3), np.uint8)
+    want[:] = np.asarray(R.BG, np.uint8)
+    d, _ = sh.linear_offset
+    R.blend_solid(want, R.unpack_mask(R.stroke_mask_closed(verts, W, H, sh.linear_pen_width / 2.0, d, d, False,
+                                                           round_join=True), W), (0, 0, 0), sh.alpha)
+    line = (R.rasterize_spans(R.spans_polyline(Y, W, H), (255, 255, 255), W, H) == 255).all(axis=2)
+    want[line] = _np(sc.pen_rgb)[f, :3]
+    assert np.array_equal(got, want)

@@ -285,9 +285,11 @@ def build_ffmpeg_cmd(width: int, height: int, fps: int, out_path: str, audio_pat
                        "-r", str(int(fps)), "-i", "pipe:0", "-i", audio_path]
     fam = dev.split(":", 1)[0] if dev else ""
     arg = dev.split(":", 1)[1] if ":" in dev else ""
-    usable = (fam in _HW and (_HW[fam][0] in enc or _HW[fam][1] in enc)
-              and (fam != "videotoolbox" or system == "Darwin") and (fam != "vaapi" or system == "Linux")
-              and (fam == "videotoolbox" or ":" in dev))
+    if fam == "videotoolbox":            # exact id, macOS only; a missing encoder is an error, not a fallback (:446-448)
+        usable = dev == "videotoolbox" and system == "Darwin"
+    else:                                # "<family>:<arg>" and at least one encoder of the family, else libx264 (:450-476)
+        usable = (fam in _HW and ":" in dev and (_HW[fam][0] in enc or _HW[fam][1] in enc)
+                  and (fam != "vaapi" or system == "Linux"))
     pix_out, vfilter = "yuv420p", None
     if usable:
         h264, hevc, flags = _HW[fam]

@@ -434,7 +434,74 @@ def capture_shadow(name, mode, kind, n, sr, fps, size, view_state, frames):
     print(f"shadow_{name}: {len(out)} arrays;", list(out[f"f{frames[0]}_calls"]))
 
 
+# the case matrix of the FFmpeg argv fixture; tests/test_host_cpu.py replays it against aurora_amd.export.exporter
+FFMPEG_SYSTEMS = ["Linux", "Darwin", "Windows"]
+FFMPEG_ENCODER_SETS = [
+    ["libx264"], ["h264_nvenc", "hevc_nvenc"], ["h264_nvenc"], ["hevc_amf"], ["h264_amf", "hevc_amf"], ["h264_qsv"],
+    ["h264_vaapi", "hevc_vaapi"], ["h264_videotoolbox", "hevc_videotoolbox"],
+    ["libx264", "h264_nvenc", "hevc_nvenc", "h264_amf", "hevc_amf", "h264_qsv", "hevc_qsv", "h264_vaapi", "hevc_vaapi",
+     "h264_videotoolbox", "hevc_videotoolbox"],
+]
+FFMPEG_DEVICES = [None, "", "cpu", "off", "0", "auto", " AUTO ", "nvenc:1", "nvenc:x", "nvenc", "amf:auto", "qsv:auto",
+                  "vaapi:/dev/dri/renderD128", "videotoolbox", "videotoolbox:0", "bogus"]
+
+
+class _FakeDri:
+    """Stands in for pathlib.Path inside the exporter module: /dev/dri with two render nodes."""
+    def __init__(self, p): self.p = str(p)
+    def exists(self): return True
+    def glob(self, pat): return [_FakeDri("/dev/dri/renderD129"), _FakeDri("/dev/dri/renderD128")]
+    def __lt__(self, o): return self.p < o.p
+    def __str__(self): return self.p
+    @property
+    def name(self): return self.p.rsplit("/", 1)[-1]
+
+
+def replay_ffmpeg_cases(mod):
+    """Runs build_ffmpeg_cmd / list_gpu_export_devices of ``mod`` (the reference's export.exporter here, the HIP
+    build's in the test) over the case matrix with the machine probes replaced: FFmpeg binary, its encoder list,
+    platform.system, nvidia-smi lookup and the /dev/dri listing."""
+    import json
+    saved = (mod._ffmpeg_bin, mod._ffmpeg_encoders, mod.platform.system, mod.shutil.which, mod.Path)
+    out = {}
+    try:
+        mod._ffmpeg_bin = lambda: "/opt/bin/ffmpeg"
+        mod.shutil.which = lambda name: None
+        mod.Path = _FakeDri
+        for system in FFMPEG_SYSTEMS:
+            mod.platform.system = lambda system=system: system
+            for k, encs in enumerate(FFMPEG_ENCODER_SETS):
+                mod._ffmpeg_encoders = lambda _bin, encs=encs: set(encs)
+                out[f"list/{system}/{k}"] = mod.list_gpu_export_devices()
+                for j, dev in enumerate(FFMPEG_DEVICES):
+                    for hevc in (False, True):
+                        outp = "clip" if (j + hevc) % 2 else "clip.mkv"
+                        try:
+                            cmd, fmt = mod.build_ffmpeg_cmd(1920, 1080, 60, outp, "in.wav", prefer_hevc=hevc,
+                                                            gpu_device=dev)
+                            res = {"cmd": list(cmd), "fmt": fmt}
+                        except RuntimeError as exc:
+                            res = {"error": str(exc)}
+                        out[f"cmd/{system}/{k}/{j}/{int(hevc)}"] = res
+    finally:
+        mod._ffmpeg_bin, mod._ffmpeg_encoders, mod.platform.system, mod.shutil.which, mod.Path = saved
+    return json.dumps(out, sort_keys=True)
+
+
+def capture_ffmpeg_cmds():
+    """`build_ffmpeg_cmd` / `list_gpu_export_devices` (export/exporter.py:368-491) over the case matrix."""
+    import export.exporter as ref
+    js = replay_ffmpeg_cases(ref)
+    np.savez_compressed(os.path.join(HERE, "ffmpeg_cmds.npz"), cases_json=np.asarray(js))
+    print(f"ffmpeg_cmds: {js.count('cmd/')} argv cases, {len(js)} bytes of JSON")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ffmpeg":         # adds the ffmpeg_cmds fixture only
+        _install_stand_ins()
+        sys.path.insert(0, REF)
+        capture_ffmpeg_cmds()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "shadow":         # adds the shadow_* fixtures only
         _install_stand_ins()
         sys.path.insert(0, REF)

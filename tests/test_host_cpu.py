@@ -346,3 +346,121 @@ def test_round_stroke_equals_distance_to_polyline():
         sure = np.abs(dist - hw) > 1e-9
         assert np.array_equal(got[sure], (dist <= hw)[sure])
         assert got.any() and not got.all()
+
+
+# ------------------------------------------------------------------ FFmpeg argv / encoder list == the reference's
+
+def test_ffmpeg_argv_and_device_list_match_reference_matrix():
+    """build_ffmpeg_cmd / list_gpu_export_devices (export/exporter.py:368-491) over 3 systems x 9 encoder sets x 16
+    device strings x h264/hevc: argv, error messages and the dropdown list equal what the reference returned
+    (tests/golden/ffmpeg_cmds.npz, made by make_golden.py's replay_ffmpeg_cases run on the reference module)."""
+    import importlib.util
+    import json
+    import os
+    from aurora_amd.export import exporter as mine
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = json.loads(str(np.load(os.path.join(here, "ffmpeg_cmds.npz"))["cases_json"]))
+    got = json.loads(mg.replay_ffmpeg_cases(mine))
+    assert got.keys() == want.keys() and len(want) == 864 + 27
+    bad = [k for k in want if got[k] != want[k]]
+    assert not bad, (bad[:5], got[bad[0]], want[bad[0]])
+
+
+class _DuckRenderer:
+    """The duck type `_run_pipe` accepts (exporter.py:536-540): .duration and .render_time(t)."""
+    def __init__(self, duration, shape):
+        self.duration, self.shape, self.times = duration, shape, []
+
+    def render_time(self, t):
+        self.times.append(t)
+        return np.full(self.shape, len(self.times), np.uint8)[:, ::1]
+
+
+def test_run_pipe_matches_reference_loop(tmp_path):
+    """Exporter._run_pipe (exporter.py:531-567) with a stand-in child process: frame bytes in order, progress every
+    max(1, int(fps / 2)) frames as int(i * 100 / total) and a final 100, non-zero exit -> RuntimeError with stderr,
+    a child that stops reading ends the loop quietly."""
+    import sys
+    from aurora_amd.export.exporter import Exporter
+    ex = Exporter("unused.wav", width=4, height=2, fps=4, mode="Spectrum - Linear")
+    out = tmp_path / "frames.bin"
+    sink_cmd = [sys.executable, "-c", f"import sys; open({str(out)!r}, 'wb').write(sys.stdin.buffer.read())"]
+    r = _DuckRenderer(2.1, (2, 4, 3))
+    seen = []
+    ex._run_pipe(r, sink_cmd, progress_cb=seen.append)
+    assert r.times == [i / 4 for i in range(9)]                        # ceil(2.1 * 4) frames at t = i / fps
+    assert out.read_bytes() == b"".join(bytes([k]) * 24 for k in range(1, 10))
+    assert seen == [0, 22, 44, 66, 88, 100]
+    # a progress callback that raises is ignored (:546-549)
+    ex._run_pipe(_DuckRenderer(0.5, (2, 4, 3)), sink_cmd, progress_cb=lambda p: 1 / 0)
+    fail_cmd = [sys.executable, "-c", "import sys; sys.stdin.buffer.read(); sys.stderr.write('boom'); sys.exit(3)"]
+    with pytest.raises(RuntimeError) as ei:
+        ex._run_pipe(_DuckRenderer(0.5, (2, 4, 3)), fail_cmd)
+    assert str(ei.value) == "ffmpeg failed (exit 3):\nboom"
+    # the child exits without reading: BrokenPipeError stops the writes, exit code 0 -> no error
+    big = Exporter("unused.wav", width=1024, height=512, fps=30, mode="Spectrum - Linear")
+    quit_cmd = [sys.executable, "-c", "import sys; sys.exit(0)"]
+    r = _DuckRenderer(3.0, (512, 1024, 3))
+    seen = []
+    big._run_pipe(r, quit_cmd, progress_cb=seen.append)
+    assert len(r.times) < 90 and seen[-1] == 100
+
+
+def test_load_audio_wav_variants_and_ffmpeg_fallback(tmp_path, monkeypatch):
+    """Audio ingest (exporter.py:108-113 with `_FFmpegDecodedAudio` :46-81): WAV files are read whole as float32
+    [n, C]; anything else goes through `ffmpeg ... -f f32le -ac 1 -ar 48000 -` (a stand-in script here), with the
+    reference's two error messages."""
+    import os
+    import stat
+    import sys
+    import wave
+    from scipy.io import wavfile
+    from aurora_amd.export import exporter as E
+    rng = np.random.default_rng(0)
+    pcm = rng.integers(-32768, 32767, (1000, 2)).astype(np.int16)
+    with wave.open(str(tmp_path / "a16.wav"), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(44100); w.writeframes(pcm.tobytes())
+    a, sr = E.load_audio(str(tmp_path / "a16.wav"))
+    assert sr == 44100 and a.dtype == np.float32 and a.shape == (1000, 2)
+    assert np.array_equal(a, pcm.astype(np.float32) / 32768.0)
+    f32 = (rng.standard_normal((777, 1)) * 0.1).astype(np.float32)
+    wavfile.write(str(tmp_path / "f32.wav"), 48000, f32[:, 0])
+    a, sr = E.load_audio(str(tmp_path / "f32.wav"))
+    assert sr == 48000 and a.shape == (777, 1) and np.array_equal(a, f32)
+    # 24-bit PCM: sample / 2^23 whichever reader takes it
+    v = rng.integers(-(1 << 23), 1 << 23, 300).astype(np.int32)
+    raw = b"".join(int(x & 0xFFFFFF).to_bytes(3, "little") for x in v)
+    with wave.open(str(tmp_path / "a24.wav"), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(3); w.setframerate(48000); w.writeframes(raw)
+    a, sr = E.load_audio(str(tmp_path / "a24.wav"))
+    assert a.shape == (300, 1) and np.array_equal(a[:, 0], v.astype(np.float32) / 8388608.0)
+    assert np.array_equal(E._read_wav_stdlib(str(tmp_path / "a24.wav"))[0], a)
+    # not a WAV: the FFmpeg decode, mono at 48 kHz
+    mp3 = tmp_path / "song.mp3"
+    mp3.write_bytes(b"ID3 not really audio")
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    pcm_out = tmp_path / "decoded.f32"
+    want = (rng.standard_normal(4321) * 0.2).astype(np.float32)
+    pcm_out.write_bytes(want.tobytes())
+    args_out = tmp_path / "args.txt"
+    script = bindir / "ffmpeg"
+    script.write_text(f"#!{sys.executable}\nimport sys\nopen({str(args_out)!r}, 'w').write('\\n'.join(sys.argv[1:]))\n"
+                      f"sys.stdout.buffer.write(open({str(pcm_out)!r}, 'rb').read())\n")
+    script.chmod(script.stat().st_mode | stat.S_IXUSR)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ.get("PATH", ""))
+    a, sr = E.load_audio(str(mp3))
+    assert sr == 48000 and a.shape == (4321, 1) and np.array_equal(a[:, 0], want)
+    assert args_out.read_text().split("\n") == ["-v", "error", "-i", str(mp3), "-f", "f32le", "-acodec", "pcm_f32le",
+                                                 "-ac", "1", "-ar", "48000", "-"]                  # exporter.py:54-58
+    script.write_text(f"#!{sys.executable}\nimport sys\nsys.stderr.write('bad input')\nsys.exit(1)\n")
+    with pytest.raises(RuntimeError) as ei:
+        E.load_audio(str(mp3))
+    assert str(ei.value) == "ffmpeg decode failed: bad input"
+    monkeypatch.setattr(E.shutil, "which", lambda name: None)
+    with pytest.raises(RuntimeError) as ei:
+        E.load_audio(str(mp3))
+    assert str(ei.value) == "ffmpeg not found for decoding non-WAV formats."

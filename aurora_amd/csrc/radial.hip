@@ -773,46 +773,39 @@ extern "C" int aur_envelope_vertices(aur_ctx* ctx, const float* d_logspec, const
 // max(10, 70 - 10 k)) (:1099-1117), no antialiasing (the hint was restored off at :1096); a = 255 overwrites (a disc
 // composited over a frame of another mode).  Arithmetic = Qt's premultiplied ARGB32 source-over,
 //   d' = div255(c a) + div255(d (255 - a)),   div255(x) = (x + (x >> 8) + 0x80) >> 8      (parity-unpinned vs Qt).
-// One thread per 32-pixel word of a frame: reads the K plane words, returns when none is set (most of the frame).
 constexpr int kBlendMaxK = 8;
 struct BlendColours {
     uint32_t pm[kBlendMaxK][3];      // premultiplied source div255(c a), per channel (computed on the host)
     uint32_t inv[kBlendMaxK];        // 255 - a
+    uint32_t pm_rb[kBlendMaxK];      // pm[k][0] | pm[k][2] << 16
 };
 __host__ __device__ __forceinline__ uint32_t div255(uint32_t x) { return (x + (x >> 8) + 0x80u) >> 8; }
 
-// One thread per 8 pixels (a quarter of a plane word): the lanes of a wave cover 512 consecutive pixels of a row, so the
-// covered part of a row keeps most of a wave busy.  VEC: the 24 bytes of the 8 pixels are 8-byte aligned (W a multiple
-// of 8 and an 8-byte aligned batch): three uint2 loads, bytes blended in registers, three uint2 stores; otherwise byte
-// accesses.
-template <bool VEC>
-__global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __restrict__ planes, int K, BlendColours col,
-                                                           int W, int H, int W32, uint8_t* __restrict__ frames) {
-    const int f = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;         // quarter word of the frame: (row * W32 + w) * 4 + q
-    if (idx >= H * W32 * 4) return;
-    const int word = idx >> 2, q = idx & 3;
-    const int row = word / W32, w = word - row * W32;
-    uint32_t m[kBlendMaxK], any = 0;
+// Each lane first reads the K plane words of one 32-pixel word of the frame (64 consecutive words per wave); a wave
+// whose 2048 pixels have no bit set (most of a frame) ends there.  Otherwise the words are parked in LDS, the
+// quarter words (8 pixels) with any bit set are queued, and the wave works the queue off 64 entries at a time, one
+// lane per 8 pixels, so the blend passes run with full lanes.  The blend arithmetic is what bounds the kernel (K x 3 channels per covered pixel), so K is a
+// template parameter (KT >= K planes are looped over) and R and B share one register: the two 16-bit products of
+// (R | B << 16) * (255 - a) and their div255 never carry into each other.
+// VEC: the 24 bytes of the 8 pixels are 8-byte aligned (W a multiple of 8 and an 8-byte aligned batch): three uint2
+// loads, bytes blended in registers, three uint2 stores; otherwise byte accesses.
+template <int KT>
+__device__ __forceinline__ void blend_pixel(const uint32_t (&m)[KT], int b, const BlendColours& col, uint32_t& rb,
+                                            uint32_t& g) {
 #pragma unroll
-    for (int k = 0; k < kBlendMaxK; ++k) {
-        m[k] = (k < K) ? (planes[(((size_t)f * K + k) * H + row) * W32 + w] >> (8 * q)) & 0xffu : 0u;
-        any |= m[k];
-    }
-    if (any == 0) return;
-    const int x0 = w * 32 + q * 8;
-    uint8_t* px = frames + (((size_t)f * H + row) * W + x0) * 3;
-    auto blend = [&](int b, uint32_t& c0, uint32_t& c1, uint32_t& c2) {
-#pragma unroll
-        for (int k = 0; k < kBlendMaxK; ++k) {
-            if ((m[k] >> b) & 1u) {
-                // operands are below 2^8: the 24-bit multiply is exact and runs at full rate (v_mul_lo_u32 at a quarter)
-                c0 = col.pm[k][0] + div255(__umul24(c0, col.inv[k]));
-                c1 = col.pm[k][1] + div255(__umul24(c1, col.inv[k]));
-                c2 = col.pm[k][2] + div255(__umul24(c2, col.inv[k]));
-            }
+    for (int k = 0; k < KT; ++k) {
+        if ((m[k] >> b) & 1u) {
+            // operands are below 2^24 / 2^8: the 24-bit multiply is exact and runs at full rate
+            const uint32_t x = __umul24(rb, col.inv[k]);
+            rb = col.pm_rb[k] + (((x + ((x >> 8) & 0x00ff00ffu) + 0x00800080u) >> 8) & 0x00ff00ffu);
+            g = col.pm[k][1] + div255(__umul24(g, col.inv[k]));
         }
-    };
+    }
+}
+
+template <bool VEC, int KT>
+__device__ __forceinline__ void blend_quarter(const uint32_t (&m)[KT], uint32_t any, const BlendColours& col, int W,
+                                              int x0, uint8_t* __restrict__ px) {
     if (VEC && x0 + 8 <= W) {
         uint2* q2 = reinterpret_cast<uint2*>(px);
         uint32_t d[6];
@@ -825,16 +818,17 @@ __global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __res
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             if ((any >> b) & 1u) {
-                uint32_t c[3];
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) c[ch] = (d[(3 * b + ch) >> 2] >> (8 * ((3 * b + ch) & 3))) & 0xffu;
-                blend(b, c[0], c[1], c[2]);
-#pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const int sh = 8 * ((3 * b + ch) & 3);
-                    uint32_t& dw = d[(3 * b + ch) >> 2];
-                    dw = (dw & ~(0xffu << sh)) | (c[ch] << sh);
-                }
+                // bytes 3b, 3b + 1, 3b + 2 of the 24: v_perm_b32 picks from {S0 (selectors 4-7), S1 (0-3)}, 0x0c = zero
+                const int ir = (3 * b) >> 2, orr = (3 * b) & 3;
+                const int ig = (3 * b + 1) >> 2, og = (3 * b + 1) & 3;
+                const int ib = (3 * b + 2) >> 2, ob = (3 * b + 2) & 3;
+                uint32_t rb = __builtin_amdgcn_perm(d[ib], d[ir], (uint32_t)orr | 0x0c000c00u | ((uint32_t)(4 + ob) << 16));
+                uint32_t g = (d[ig] >> (8 * og)) & 0xffu;
+                blend_pixel<KT>(m, b, col, rb, g);
+                const uint32_t keep = 0x03020100u;
+                d[ir] = __builtin_amdgcn_perm(rb, d[ir], (keep & ~(0xffu << (8 * orr))) | (4u << (8 * orr)));
+                d[ig] = __builtin_amdgcn_perm(g, d[ig], (keep & ~(0xffu << (8 * og))) | (4u << (8 * og)));
+                d[ib] = __builtin_amdgcn_perm(rb, d[ib], (keep & ~(0xffu << (8 * ob))) | (6u << (8 * ob)));
             }
         }
 #pragma unroll
@@ -845,12 +839,76 @@ __global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __res
         const int b = __builtin_ctz(any);
         any &= any - 1;
         if (x0 + b >= W) break;
-        uint32_t c0 = px[3 * b], c1 = px[3 * b + 1], c2 = px[3 * b + 2];
-        blend(b, c0, c1, c2);
-        px[3 * b] = (uint8_t)c0;
-        px[3 * b + 1] = (uint8_t)c1;
-        px[3 * b + 2] = (uint8_t)c2;
+        uint32_t rb = (uint32_t)px[3 * b] | ((uint32_t)px[3 * b + 2] << 16), g = px[3 * b + 1];
+        blend_pixel<KT>(m, b, col, rb, g);
+        px[3 * b] = (uint8_t)rb;
+        px[3 * b + 1] = (uint8_t)g;
+        px[3 * b + 2] = (uint8_t)(rb >> 16);
     }
+}
+
+template <bool VEC, int KT>
+__global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __restrict__ planes, int K, BlendColours col,
+                                                           int W, int H, int W32, uint8_t* __restrict__ frames) {
+    __shared__ uint32_t s_w[4][KT + 1][64];
+    __shared__ uint8_t s_q[4][256];
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int words = H * W32;
+    const int word0 = blockIdx.x * 256 + wave * 64;         // first word of this wave
+    if (word0 >= words) return;                             // wave-uniform
+    const int mine = (word0 + lane < words) ? word0 + lane : words - 1;
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        uint32_t v = 0;
+        if (k < K && word0 + lane < words) v = planes[((size_t)f * K + k) * words + mine];
+        s_w[wave][k][lane] = v;
+        any |= v;
+    }
+    if (__ballot(any != 0) == 0) return;                    // wave-uniform
+    s_w[wave][KT][lane] = any;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the non-empty quarter words of the wave's 256, compacted so that the blend passes run with full lanes
+    int n = 0;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int id = pass * 64 + lane;                    // word id >> 2 of the wave, quarter id & 3
+        const bool on = ((s_w[wave][KT][id >> 2] >> (8 * (id & 3))) & 0xffu) != 0;
+        const uint64_t bal = __ballot(on);
+        const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (on) s_q[wave][pos] = (uint8_t)id;
+        n += __popcll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+    for (int base = 0; base < n; base += 64) {
+        if (base + lane >= n) continue;
+        const int id = s_q[wave][base + lane];
+        const int src = id >> 2, q = id & 3;
+        const uint32_t a8 = (s_w[wave][KT][src] >> (8 * q)) & 0xffu;
+        const int word = word0 + src;
+        const int row = word / W32, w = word - row * W32;
+        uint32_t m[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) m[k] = (s_w[wave][k][src] >> (8 * q)) & 0xffu;
+        const int x0 = w * 32 + q * 8;
+        blend_quarter<VEC, KT>(m, a8, col, W, x0, frames + (((size_t)f * H + row) * W + x0) * 3);
+    }
+}
+
+template <int KT>
+static void launch_blend(bool vec, dim3 grid, hipStream_t st, const uint32_t* planes, int K, const BlendColours& col,
+                         int W, int H, int W32, uint8_t* frames) {
+    if (vec)
+        hipLaunchKernelGGL((blend_planes_kernel<true, KT>), grid, dim3(256), 0, st, planes, K, col, W, H, W32, frames);
+    else
+        hipLaunchKernelGGL((blend_planes_kernel<false, KT>), grid, dim3(256), 0, st, planes, K, col, W, H, W32, frames);
 }
 
 extern "C" int aur_wave_linear_vertices(aur_ctx* ctx, const float* d_samples, const int32_t* d_col2samp,
@@ -925,15 +983,16 @@ extern "C" int aur_blend_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, c
         const uint32_t a = h_rgba[4 * k + 3];
         for (int ch = 0; ch < 3; ++ch) col.pm[k][ch] = div255((uint32_t)h_rgba[4 * k + ch] * a);
         col.inv[k] = 255u - a;
+        col.pm_rb[k] = col.pm[k][0] | (col.pm[k][2] << 16);
     }
     const int W32 = (W + 31) / 32;
-    const dim3 grid((H * W32 * 4 + 255) / 256, n_frames);
-    if (W % 8 == 0 && ((uintptr_t)d_frames & 7u) == 0)
-        hipLaunchKernelGGL(blend_planes_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, d_planes, K, col, W, H,
-                           W32, d_frames);
-    else
-        hipLaunchKernelGGL(blend_planes_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, d_planes, K, col, W, H,
-                           W32, d_frames);
+    const dim3 grid((H * W32 + 255) / 256, n_frames);       // one lane per 32-pixel word
+    const bool vec = W % 8 == 0 && ((uintptr_t)d_frames & 7u) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 1) launch_blend<1>(vec, grid, st, d_planes, K, col, W, H, W32, d_frames);          // fill, shadow
+    else if (K <= 6) launch_blend<6>(vec, grid, st, d_planes, K, col, W, H, W32, d_frames);     // feather rings
+    else if (K == 7) launch_blend<7>(vec, grid, st, d_planes, K, col, W, H, W32, d_frames);     // disc + rings
+    else launch_blend<kBlendMaxK>(vec, grid, st, d_planes, K, col, W, H, W32, d_frames);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
 
 // Even-odd fill of the implicitly closed polygon verts[f][nv][2].  The edges append their
 // crossings to the lists of the few pixel rows they span, a thread per row sorts its list into pixel spans in LDS;
-// then each wave writes its 64 rows word by word, one coalesced row at a time.  Every word of the plane is written,
+// then the block writes its rows word by word as one contiguous piece of the plane.  Every word of the plane is written,
 // so the plane needs no clearing.
 __device__ __forceinline__ int span_edge(double x, int W) {
     const double a = fmin(fmax(x, -kBig), kBig);
@@ -481,7 +481,7 @@ __device__ __forceinline__ int span_edge(double x, int W) {
 // circular path, whose spikes can cross a row near the top or bottom tangent dozens of times.
 template <int ROWS, int CROSS>
 __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restrict__ verts, int nv, int W, int H,
-                                                           int W32, uint32_t* __restrict__ planes) {
+                                                           int W32, int vec_ok, uint32_t* __restrict__ planes) {
     // sorted crossings of each row (+1: rows on different banks); once sorted they are converted in place to clipped
     // pixel-span edges (int i overlays the first half of double i / 2, which has been read by then)
     __shared__ double s_xs[ROWS][CROSS + 1];
@@ -495,6 +495,7 @@ __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restr
     // the append order does not matter (lists longer than CROSS keep an unspecified subset).
     const int base = blockIdx.x * ROWS;
     if (threadIdx.x < ROWS) s_cnt[threadIdx.x] = 0;
+    int found = 0;
     __syncthreads();
     for (int e = threadIdx.x; e < nv; e += 128) {
         const int ep = (e == 0) ? nv - 1 : e - 1;
@@ -513,10 +514,22 @@ __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restr
                 const double x = x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0);
                 const int slot = atomicAdd(&s_cnt[r - base], 1);
                 if (slot < CROSS) s_xs[r - base][slot] = x;
+                found = 1;
             }
         }
     }
-    __syncthreads();
+    const int rows_here = (H - base < ROWS) ? H - base : ROWS;
+    const int total = rows_here * W32;
+    uint32_t* dst = planes + ((long)f * H + base) * W32;
+    if (__syncthreads_or(found) == 0) {                               // no edge crosses these rows: zeros
+        if (vec_ok) {                                                 // W32 % 4 == 0 and a 16-byte aligned plane
+            uint4* d4 = reinterpret_cast<uint4*>(dst);
+            for (int idx = threadIdx.x; idx < total / 4; idx += 128) d4[idx] = uint4{0u, 0u, 0u, 0u};
+        } else {
+            for (int idx = threadIdx.x; idx < total; idx += 128) dst[idx] = 0u;
+        }
+        return;
+    }
     if (threadIdx.x < ROWS) {
         int m = s_cnt[threadIdx.x];
         if (m > CROSS) m = CROSS;
@@ -539,24 +552,23 @@ __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restr
         s_cnt[threadIdx.x] = m;
     }
     __syncthreads();
-    // each of the two waves writes half of the block's rows, one coalesced row at a time
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int rr = wave * (ROWS / 2); rr < (wave + 1) * (ROWS / 2); ++rr) {
-        const int row = base + rr;
-        if (row >= H) break;
+    // the block's rows are one contiguous piece of the plane: the threads write it word by word (128 consecutive words
+    // per step, independent steps, so the LDS reads of several steps overlap)
+    const uint32_t inv = 0xffffffffu / (uint32_t)W32 + 1u;            // idx / W32 == (idx * inv) >> 32 for idx < 2^16
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < total; idx += 128) {
+        const int rr = (int)__umulhi((uint32_t)idx, inv);
+        const int w = idx - rr * W32;
         const int cnt = s_cnt[rr];
         const int* cs = reinterpret_cast<const int*>(s_xs[rr]);
-        uint32_t* dst = planes + ((long)f * H + row) * W32;
-        for (int w = lane; w < W32; w += 64) {
-            uint32_t bits = 0;
-            for (int i = 0; i < cnt; i += 2) {            // pixel centre px + 0.5 in [x_i, x_i+1)
-                const int c0 = cs[i], c1 = cs[i + 1];
-                const int a = c0 > 32 * w ? c0 : 32 * w;
-                const int b = c1 < 32 * w + 32 ? c1 : 32 * w + 32;
-                if (b > a) bits |= (0xffffffffu >> (32 - (b - a))) << (a - 32 * w);
-            }
-            dst[w] = bits;
+        uint32_t bits = 0;
+        for (int i = 0; i < cnt; i += 2) {                // pixel centre px + 0.5 in [x_i, x_i+1)
+            const int c0 = cs[i], c1 = cs[i + 1];
+            const int a = c0 > 32 * w ? c0 : 32 * w;
+            const int b = c1 < 32 * w + 32 ? c1 : 32 * w + 32;
+            if (b > a) bits |= (0xffffffffu >> (32 - (b - a))) << (a - 32 * w);
         }
+        dst[idx] = bits;
     }
 }
 
@@ -1039,12 +1051,13 @@ extern "C" int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_verti
     AUR_REQUIRE(d_verts && d_plane, "aur_mask_polygon: null device pointer");
     const int W32 = (W + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
+    const int vec_ok = (W32 % 4 == 0 && ((uintptr_t)d_plane & 15u) == 0) ? 1 : 0;   // rows of empty blocks as uint4
     if (n_vertices <= 384)      // envelopes and feather rings
         hipLaunchKernelGGL((mask_polygon_kernel<128, 32>), dim3((H + 127) / 128, n_frames), dim3(128), 0, st, d_verts,
-                           n_vertices, W, H, W32, d_plane);
+                           n_vertices, W, H, W32, vec_ok, d_plane);
     else                        // fill polygon of the radial / circular path
         hipLaunchKernelGGL((mask_polygon_kernel<32, 256>), dim3((H + 31) / 32, n_frames), dim3(128), 0, st, d_verts,
-                           n_vertices, W, H, W32, d_plane);
+                           n_vertices, W, H, W32, vec_ok, d_plane);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -815,9 +815,10 @@ __device__ __forceinline__ void blend_pixel(const uint32_t (&m)[KT], int b, cons
     }
 }
 
-template <bool VEC, int KT>
-__device__ __forceinline__ void blend_quarter(const uint32_t (&m)[KT], uint32_t any, const BlendColours& col, int W,
-                                              int x0, uint8_t* __restrict__ px) {
+// Read-modify-write of the covered pixels (bits of `any`) of one quarter word: op(b, rb, g) updates pixel b held as
+// R | B << 16 and G.
+template <bool VEC, class Op>
+__device__ __forceinline__ void quarter_rmw(uint32_t any, const Op& op, int W, int x0, uint8_t* __restrict__ px) {
     if (VEC && x0 + 8 <= W) {
         uint2* q2 = reinterpret_cast<uint2*>(px);
         uint32_t d[6];
@@ -836,7 +837,7 @@ __device__ __forceinline__ void blend_quarter(const uint32_t (&m)[KT], uint32_t 
                 const int ib = (3 * b + 2) >> 2, ob = (3 * b + 2) & 3;
                 uint32_t rb = __builtin_amdgcn_perm(d[ib], d[ir], (uint32_t)orr | 0x0c000c00u | ((uint32_t)(4 + ob) << 16));
                 uint32_t g = (d[ig] >> (8 * og)) & 0xffu;
-                blend_pixel<KT>(m, b, col, rb, g);
+                op(b, rb, g);
                 const uint32_t keep = 0x03020100u;
                 d[ir] = __builtin_amdgcn_perm(rb, d[ir], (keep & ~(0xffu << (8 * orr))) | (4u << (8 * orr)));
                 d[ig] = __builtin_amdgcn_perm(g, d[ig], (keep & ~(0xffu << (8 * og))) | (4u << (8 * og)));
@@ -852,7 +853,7 @@ __device__ __forceinline__ void blend_quarter(const uint32_t (&m)[KT], uint32_t 
         any &= any - 1;
         if (x0 + b >= W) break;
         uint32_t rb = (uint32_t)px[3 * b] | ((uint32_t)px[3 * b + 2] << 16), g = px[3 * b + 1];
-        blend_pixel<KT>(m, b, col, rb, g);
+        op(b, rb, g);
         px[3 * b] = (uint8_t)rb;
         px[3 * b + 1] = (uint8_t)g;
         px[3 * b + 2] = (uint8_t)(rb >> 16);
@@ -910,7 +911,8 @@ __global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __res
 #pragma unroll
         for (int k = 0; k < KT; ++k) m[k] = (s_w[wave][k][src] >> (8 * q)) & 0xffu;
         const int x0 = w * 32 + q * 8;
-        blend_quarter<VEC, KT>(m, a8, col, W, x0, frames + (((size_t)f * H + row) * W + x0) * 3);
+        quarter_rmw<VEC>(a8, [&](int b, uint32_t& rb, uint32_t& g) { blend_pixel<KT>(m, b, col, rb, g); }, W, x0,
+                         frames + (((size_t)f * H + row) * W + x0) * 3);
     }
 }
 
@@ -921,6 +923,57 @@ static void launch_blend(bool vec, dim3 grid, hipStream_t st, const uint32_t* pl
         hipLaunchKernelGGL((blend_planes_kernel<true, KT>), grid, dim3(256), 0, st, planes, K, col, W, H, W32, frames);
     else
         hipLaunchKernelGGL((blend_planes_kernel<false, KT>), grid, dim3(256), 0, st, planes, K, col, W, H, W32, frames);
+}
+
+// ---- additive planes (glow) ----------------------------------------------------------------------------------------
+// `_draw_glow_offscreen` (rt_widget.py:634-653): up to kAddMaxK strokes of the same path with pens of growing width and
+// falling alpha, CompositionMode_Plus.  Layer k of frame f adds its premultiplied colour pm[f][k] (r | g << 8 | b << 16,
+// div255(c a) computed on the host from the frame's energy) to every pixel of its plane, each channel saturating at 255
+// (Qt's comp_func_Plus on premultiplied ARGB32 with an opaque destination; saturating after every layer equals saturating
+// the sum).  Planes are layer-major, uint32 [K][F][H][W32], so that a layer is one aur_mask_stroke_path call.
+// One lane per 32-pixel word; lanes whose word has no bit in any layer (most of a frame) stop after the K loads.
+constexpr int kAddMaxK = 16;
+template <bool VEC>
+__global__ __launch_bounds__(256) void add_planes_kernel(const uint32_t* __restrict__ planes, int K, size_t layer_stride,
+                                                         const uint32_t* __restrict__ pm, int W, int H, int W32,
+                                                         uint8_t* __restrict__ frames) {
+    const int f = blockIdx.y;
+    const int words = H * W32;
+    const int word = blockIdx.x * 256 + threadIdx.x;
+    if (word >= words) return;
+    uint32_t m[kAddMaxK], any = 0;
+#pragma unroll
+    for (int k = 0; k < kAddMaxK; ++k) {
+        m[k] = k < K ? planes[k * layer_stride + (size_t)f * words + word] : 0u;
+        any |= m[k];
+    }
+    if (any == 0) return;
+    uint32_t crb[kAddMaxK], cg[kAddMaxK];
+#pragma unroll
+    for (int k = 0; k < kAddMaxK; ++k) {
+        const uint32_t c = k < K ? pm[(size_t)f * K + k] : 0u;      // block-uniform
+        crb[k] = c & 0x00ff00ffu;
+        cg[k] = (c >> 8) & 0xffu;
+    }
+    const int row = word / W32, w = word - row * W32;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t a8 = (any >> (8 * q)) & 0xffu;
+        if (a8 == 0) continue;
+        const int x0 = w * 32 + q * 8;
+        quarter_rmw<VEC>(a8, [&](int b, uint32_t& rb, uint32_t& g) {
+            uint32_t srb = rb, sg = g;                               // at most 255 + 16 * 255 per 16-bit half
+#pragma unroll
+            for (int k = 0; k < kAddMaxK; ++k) {
+                const uint32_t on = 0u - ((m[k] >> (8 * q + b)) & 1u);
+                srb += crb[k] & on;
+                sg += cg[k] & on;
+            }
+            const uint32_t r = min(srb & 0xffffu, 255u), bl = min(srb >> 16, 255u);
+            rb = r | (bl << 16);
+            g = min(sg, 255u);
+        }, W, x0, frames + (((size_t)f * H + row) * W + x0) * 3);
+    }
 }
 
 extern "C" int aur_wave_linear_vertices(aur_ctx* ctx, const float* d_samples, const int32_t* d_col2samp,
@@ -1005,6 +1058,31 @@ extern "C" int aur_blend_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, c
     else if (K <= 6) launch_blend<6>(vec, grid, st, d_planes, K, col, W, H, W32, d_frames);     // feather rings
     else if (K == 7) launch_blend<7>(vec, grid, st, d_planes, K, col, W, H, W32, d_frames);     // disc + rings
     else launch_blend<kBlendMaxK>(vec, grid, st, d_planes, K, col, W, H, W32, d_frames);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_add_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t* d_pm_rgb, int n_frames,
+                             int W, int H, uint8_t* d_frames, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(K >= 1 && K <= kAddMaxK, "aur_add_planes: K %d outside [1, %d]", K, kAddMaxK);
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_add_planes: n_frames %d outside [0, 65535]", n_frames);
+    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_add_planes: frame size %dx%d unsupported", W, H);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_planes && d_pm_rgb && d_frames, "aur_add_planes: null device pointer");
+    AUR_REQUIRE(((uintptr_t)d_pm_rgb & 3u) == 0, "aur_add_planes: colour table not 4-byte aligned");
+    const int W32 = (W + 31) / 32;
+    const size_t layer_stride = (size_t)n_frames * H * W32;
+    const dim3 grid((H * W32 + 255) / 256, n_frames);
+    const bool vec = W % 8 == 0 && ((uintptr_t)d_frames & 7u) == 0;
+    const uint32_t* pm = reinterpret_cast<const uint32_t*>(d_pm_rgb);
+    if (vec)
+        hipLaunchKernelGGL((add_planes_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, d_planes, K, layer_stride,
+                           pm, W, H, W32, d_frames);
+    else
+        hipLaunchKernelGGL((add_planes_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, d_planes, K,
+                           layer_stride, pm, W, H, W32, d_frames);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

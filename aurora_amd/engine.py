@@ -216,6 +216,68 @@ class ShadowConfig:
         return d, d
 
 
+@dataclass
+class GlowConfig:
+    """`_draw_glow_path` / `_draw_glow_offscreen` (rt_widget.py:598-616, :634-653) as an export configures it
+    (export/exporter.py:196-199; the export always takes the offscreen branch, exporter.py:118): the closed path of
+    "Spectrum - Radial" / "Waveform - Circular" stroked `layers` times, CompositionMode_Plus, before its own stroke."""
+    enabled: bool = False
+    rgba: tuple = (0xA0, 0xFF, 0xFF, 0x80)   # '#80A0FFFF', exporter.py:197
+    radius: int = 22
+    strength: float = 0.8
+    layers: int = 8                          # rt_widget.py:91; no setter, no view_state key
+
+    @classmethod
+    def from_view_state(cls, vs):
+        vs = vs or {}
+        c = cls()
+        c.enabled = bool(vs.get("glow_enabled", False))
+        # an invalid string keeps the widget's own default (rt_widget.py:88, :343-346)
+        c.rgba = FillConfig.parse_colour(vs.get("glow_color", "#80A0FFFF"), (80, 220, 255, 255))
+        c.radius = int(max(0, int(vs.get("glow_radius", 22))))                           # :349-351
+        c.strength = max(0.0, min(1.0, float(int(vs.get("glow_strength", 80))) / 100.0)) # :356-358
+        return c
+
+    @property
+    def active(self):
+        return self.enabled and self.radius > 0 and self.strength > 0.0                  # :599-604
+
+    @property
+    def base_alpha(self):
+        """QColor.alphaF(): Qt 6 keeps 16 bits per channel (a * 0x101) and returns alpha / 65535 as a C float."""
+        a = np.float32(int(self.rgba[3]) * 257) / np.float32(65535)
+        return max(0.0, min(1.0, float(a)))                                              # :612
+
+    def layer_table(self):
+        """[(pen width, falloff)] of the layers that can paint (falloff > 0), in paint order (:635-648)."""
+        n = max(4, min(16, int(self.layers)))
+        out = []
+        for i in range(n):
+            t = i / float(max(1, n - 1))
+            falloff = (1.0 - t) ** 2
+            if falloff > 0.0:
+                out.append((max(3, int(2 + self.radius * (0.35 + 0.9 * t))), falloff))
+        return out
+
+    def layer_alpha(self, energy: np.ndarray) -> np.ndarray:
+        """Pen alpha int64 [F, K] of every layer from the frames' energy (float64 [F]), the reference's expression
+        order (:606-607, :642); 0 = the layer is skipped in that frame (:643-644)."""
+        e = np.asarray(energy, dtype=np.float64)
+        intensity = self.strength * (0.15 + 0.85 * np.maximum(0.0, np.minimum(1.0, e)))
+        ba = self.base_alpha
+        cols = [np.trunc(255 * ba * intensity * 0.55 * falloff) for _, falloff in self.layer_table()]
+        return np.maximum(np.stack(cols, axis=1), 0.0).astype(np.int64)
+
+    def layer_premultiplied(self, energy: np.ndarray) -> np.ndarray:
+        """uint8 [F, K, 4]: qPremultiply of the pen colour of every layer, (div255(r a), div255(g a), div255(b a), 0)."""
+        a = self.layer_alpha(energy)
+        out = np.zeros(a.shape + (4,), dtype=np.uint8)
+        for ch in range(3):
+            x = int(self.rgba[ch]) * a
+            out[..., ch] = (x + (x >> 8) + 0x80) >> 8
+        return out
+
+
 def angle_table(n: int, rotation_deg: float) -> np.ndarray:
     """(cos a_i, sin a_i), a_i = 2 pi (i / n) - pi / 2 + deg2rad(rot), i = 0..n, float64 [n + 1, 2], evaluated with the
     reference's expression and scalar calls (rt_widget.py:966, :1035) -- an index-map-like table, so it is exact."""
@@ -570,6 +632,29 @@ class HipExportEngine:
                                               None, count, W, H, st), "aur_plane_exclude")
         return self.blend_planes(plane, bytes((0, 0, 0, shadow.alpha)), frames)
 
+    def apply_glow(self, glow: GlowConfig, verts, sc: Scan, first: int, count: int, excl_a, excl_b, excl_b_static,
+                   frames):
+        """`_draw_glow_offscreen` of the closed path ``verts`` float64 [count, n, 2]: one RoundJoin stroke plane per
+        layer, added (CompositionMode_Plus) in the layer's premultiplied colour wherever the planes ``excl_a`` /
+        ``excl_b`` (stroke and disc, painted afterwards with opaque colours) have no bit (in place)."""
+        torch = self.torch
+        H, W = int(frames.shape[1]), int(frames.shape[2])
+        W32 = (W + 31) // 32
+        h, st = self.ctx.handle, self.stream()
+        table = glow.layer_table()
+        K = len(table)
+        energy = sc.energy[first:first + count].cpu().numpy()
+        pm = torch.from_numpy(glow.layer_premultiplied(energy)).to(self.device)
+        planes = self.empty((K, count, H, W32), torch.int32)
+        for k, (width, _) in enumerate(table):
+            _lib.check(self.lib.aur_mask_stroke_path(h, _ptr(verts), int(verts.shape[1]), count, W, H, width / 2.0,
+                                                     0.0, 0.0, 1, 1, _ptr(planes[k]), st), "aur_mask_stroke_path")
+            _lib.check(self.lib.aur_plane_exclude(h, _ptr(planes[k]), _ptr(excl_a), _ptr(excl_b),
+                                                  int(bool(excl_b_static)), None, count, W, H, st), "aur_plane_exclude")
+        _lib.check(self.lib.aur_add_planes(h, _ptr(planes), K, _ptr(pm), count, W, H, _ptr(frames), st),
+                   "aur_add_planes")
+        return frames
+
     # QColor(13, 13, 18) with alpha max(10, 70 - 10 k), k = 1..6 (rt_widget.py:1099, :1116)
     FEATHER_RGBA = bytes(v for k in range(1, 7) for v in (13, 13, 18, max(10, 70 - 10 * k)))
     DISC_RGBA = bytes((30, 30, 40, 255))                                    # rt_widget.py:1092/1094
@@ -651,22 +736,26 @@ class HipExportEngine:
 
     def render_radial(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int = 0,
                       count: int | None = None, out=None, planes_out=None, fill: FillConfig | None = None,
-                      shadow: ShadowConfig | None = None):
+                      shadow: ShadowConfig | None = None, glow: GlowConfig | None = None):
         """Frames uint8 [count, H, W, 3] of "Spectrum - Radial" (paint_frame, rt_widget.py:821-852).  The reference's
-        order is fill, path shadow, stroke, envelope shadow, disc, feather rings; stroke and disc are opaque, so the
-        translucent layers are applied afterwards where those two do not cover them."""
+        order is fill, path shadow, glow, stroke, envelope shadow, disc, feather rings; stroke and disc are opaque, so
+        the translucent layers are applied afterwards where those two do not cover them."""
         if count is None:
             count = an.n_frames - first
         planes = self.radial_planes(prep, an, sc, W, H, first, count, planes_out)
         out = self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
         want_fill = fill is not None and fill.enabled
         want_shadow = shadow is not None and shadow.active
-        if want_fill or want_shadow:
+        want_glow = glow is not None and glow.active
+        if want_fill or want_shadow or want_glow:
             verts = self.radial_path_vertices(prep, sc, W, H, first, count)
         if want_fill:
             self.apply_fill(fill, verts, sc, first, count, planes[0], planes[1], planes[2], out)
         if want_shadow:
             self.apply_shadow(shadow, verts, True, planes[0], planes[1], planes[2], out)          # :978-979
+        if want_glow:
+            self.apply_glow(glow, verts, sc, first, count, planes[0], planes[1], planes[2], out)  # :980
+        if want_shadow:
             env = self._envelope(prep, an, sc, W, H, first, count)
             self.apply_shadow(shadow, env, False, None, planes[1], planes[2], out)                # :1053-1054
         if prep.cfg.feather_enabled:
@@ -735,7 +824,7 @@ class HipExportEngine:
 
     def render_wave_circular(self, an: Analysis, sc: Scan, W: int, H: int, first: int = 0, count: int | None = None,
                              rotation_deg: float = 0.0, out=None, planes_out=None, fill: FillConfig | None = None,
-                             shadow: ShadowConfig | None = None):
+                             shadow: ShadowConfig | None = None, glow: GlowConfig | None = None):
         """Frames uint8 [count, H, W, 3] of "Waveform - Circular" (paint_frame, rt_widget.py:821-852)."""
         if count is None:
             count = an.n_frames - first
@@ -743,12 +832,15 @@ class HipExportEngine:
         out = self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
         want_fill = fill is not None and fill.enabled
         want_shadow = shadow is not None and shadow.active
-        if want_fill or want_shadow:
+        want_glow = glow is not None and glow.active
+        if want_fill or want_shadow or want_glow:
             verts = self.wave_circular_vertices(an, sc, W, H, first, count, rotation_deg)
         if want_fill:
             self.apply_fill(fill, verts, sc, first, count, planes[0], None, True, out)            # :898
         if want_shadow:
             self.apply_shadow(shadow, verts, True, planes[0], None, True, out)                    # :899-900
+        if want_glow:
+            self.apply_glow(glow, verts, sc, first, count, planes[0], None, True, out)            # :901
         return out
 
     # ------------------------------------------------------------------ streaming Analyzer step

@@ -19,7 +19,7 @@ import threading
 import numpy as np
 
 from . import _lib
-from .engine import FillConfig, ShadowConfig, HipExportEngine, PLANE_KINDS, RadialConfig, Track, mode_kind, SUPPORTED_KINDS
+from .engine import FillConfig, GlowConfig, ShadowConfig, HipExportEngine, PLANE_KINDS, RadialConfig, Track, mode_kind, SUPPORTED_KINDS
 
 
 class NullSink:
@@ -71,7 +71,8 @@ class FramePipeline:
                  sensitivity: float = 1.0, frame_begin: int = 0, frame_end: int | None = None,
                  batch_frames: int | None = None, slots: int = 2, scan_params: _lib.ScanParams | None = None,
                  radial: "RadialConfig | None" = None, rotation_deg: float = 0.0, wire_format: str = "rgb24",
-                 fill: "FillConfig | None" = None, shadow: "ShadowConfig | None" = None):
+                 fill: "FillConfig | None" = None, shadow: "ShadowConfig | None" = None,
+                 glow: "GlowConfig | None" = None):
         self.eng = engine
         self.track = track
         self.mode = mode
@@ -102,6 +103,8 @@ class FramePipeline:
         # RoundCap / RoundJoin variant (rt_widget.py:915-930)
         self.shadow = shadow if (shadow is not None and shadow.active and
                                  (self.planes or self.kind == "waveform_linear")) else None
+        # `_draw_glow_path` is only called for the closed paths (rt_widget.py:901, :980)
+        self.glow = glow if (glow is not None and glow.active and self.planes) else None
         self._analysed = None
         self._radial_prep = None
 
@@ -127,13 +130,13 @@ class FramePipeline:
     def _render(self, an, sc, first, count, out=None, scratch=None):
         if self.radial is not None:
             return self.eng.render_radial(self._radial_prep, an, sc, self.W, self.H, first, count, out=out,
-                                          planes_out=scratch, fill=self.fill, shadow=self.shadow)
+                                          planes_out=scratch, fill=self.fill, shadow=self.shadow, glow=self.glow)
         if self.kind == "waveform_linear" and self.shadow is not None:
             n = an.n_frames - first if count is None else count
             return self.eng.render_wave_linear_shadow(an, sc, self.W, self.H, first, n, self.shadow, out=out)
         if self.kind == "waveform_circular":
             return self.eng.render_wave_circular(an, sc, self.W, self.H, first, count, self.rotation_deg, out=out,
-                                                 planes_out=scratch, fill=self.fill, shadow=self.shadow)
+                                                 planes_out=scratch, fill=self.fill, shadow=self.shadow, glow=self.glow)
         return self.eng.render(self.mode, an, sc, self.W, self.H, first, count, out=out, spans_out=scratch)
 
     # ---- full pipeline: GPU -> pinned host ring -> sink --------------------------------------------------

@@ -505,3 +505,58 @@ def render_wave_circular_frame(path_verts, pen_rgb, w, h, bg=BG):
     frame[:] = np.asarray(bg, dtype=np.uint8)
     frame[unpack_mask(stroke_mask_closed(path_verts, w, h), w)] = np.asarray(pen_rgb, dtype=np.uint8)
     return frame
+
+
+# ----------------------------------------------------------------------------- glow decoration
+# `_draw_glow_path` -> `_draw_glow_offscreen` (widgets/rt_widget.py:598-616, :634-653; the export always runs with
+# _offscreen_paint, export/exporter.py:118): after fill and path shadow, before the path's own stroke, the closed path is
+# stroked once per layer with a RoundCap / RoundJoin pen, CompositionMode_Plus.  Coverage here is aliased like the rest of
+# this rasteriser (pixel centre within half the pen width of the polyline = stroke_mask_closed(round_join=True)); the
+# reference turns antialiasing on for these strokes, which is NOT reproduced (Qt coverage is parity-unpinned anyway).
+# Pen colours, widths, composition mode and call order are pinned by tests/golden/glow_*.npz.
+
+def qcolor_alpha_f(alpha: int) -> float:
+    """QColor.alphaF() of an 8-bit alpha: Qt 6 keeps a * 0x101 and returns it / 65535 as a C float (the stand-in QColor
+    of tests/golden/make_golden.py models the same; PySide6 is not installed, so this step is unpinned against Qt)."""
+    return float(np.float32(int(alpha) * 257) / np.float32(65535))
+
+
+def glow_pens(energy: float, rgba=(0xA0, 0xFF, 0xFF, 0x80), radius: int = 22, strength: float = 0.8, layers: int = 8):
+    """[(pen width, alpha)] of the layers `_draw_glow_offscreen` paints in one frame, in paint order (rt_widget.py:599-612,
+    :635-648); empty when the glow does not paint at all."""
+    if radius <= 0 or strength <= 0.0:
+        return []
+    audio_intensity = 0.15 + 0.85 * max(0.0, min(1.0, energy))
+    intensity = strength * audio_intensity
+    if intensity <= 0.0:
+        return []
+    base_alpha = max(0.0, min(1.0, qcolor_alpha_f(rgba[3])))
+    n = max(4, min(16, layers))
+    out = []
+    for i in range(n):
+        t = i / float(max(1, n - 1))
+        falloff = (1.0 - t) ** 2
+        a = int(255 * base_alpha * intensity * 0.55 * falloff)
+        if a <= 0:
+            continue
+        out.append((max(3, int(2 + radius * (0.35 + 0.9 * t))), a))
+    return out
+
+
+def add_solid(frame, mask_bool, rgb, alpha):
+    """CompositionMode_Plus of the constant colour (rgb, alpha) on the pixels of ``mask_bool``, in place: the
+    premultiplied source div255(c a) is added per channel and saturates at 255 (Qt comp_func_Plus, opaque destination)."""
+    c = np.asarray(rgb, dtype=np.uint32)
+    pm = _div255(c * np.uint32(alpha))
+    d = frame[mask_bool].astype(np.uint32)
+    frame[mask_bool] = np.minimum(d + pm, 255).astype(np.uint8)
+
+
+def apply_glow(frame, path_verts, energy, keep_bool, w, h, rgba=(0xA0, 0xFF, 0xFF, 0x80), radius=22, strength=0.8,
+               layers=8):
+    """Glow of the closed path on ``frame`` (in place), restricted to the pixels ``keep_bool`` (those that neither the
+    stroke nor the disc, painted afterwards with opaque colours, cover)."""
+    for width, alpha in glow_pens(energy, rgba, radius, strength, layers):
+        m = unpack_mask(stroke_mask_closed(path_verts, w, h, half_width=width / 2.0, closed=True, round_join=True), w)
+        add_solid(frame, m & keep_bool, rgba[:3], alpha)
+    return frame

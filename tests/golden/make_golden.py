@@ -90,6 +90,8 @@ class QColor:
     def green(self): return self.g
     def blue(self): return self.b
     def alpha(self): return self.a
+    # Qt 6 stores 16 bits per channel (a * 0x101) and alphaF() returns alpha / 65535 as a C float
+    def alphaF(self): return float(np.float32(self.a * 257) / np.float32(65535))
     def isValid(self): return self._valid
     def setAlpha(self, a): self.a = int(a)
     def name(self, *_): return "#%02x%02x%02x%02x" % (self.a, self.r, self.g, self.b)
@@ -434,6 +436,55 @@ def capture_shadow(name, mode, kind, n, sr, fps, size, view_state, frames):
     print(f"shadow_{name}: {len(out)} arrays;", list(out[f"f{frames[0]}_calls"]))
 
 
+def capture_glow(name, mode, kind, n, sr, fps, size, view_state, frames, sensitivity=1.0):
+    """`_draw_glow_path` -> `_draw_glow_offscreen` (rt_widget.py:598-616, :634-653): the pens of every frame (colour with
+    its energy-dependent alpha, width, cap / join), composition mode, render hint and the order of the calls."""
+    from export.exporter import QPainterOffscreenRenderer
+    audio = _track(kind, n, sr, 2)
+    path = f"mem://glow_{name}"
+    _AUDIO[path] = (audio, sr)
+    w, h = size
+    r = QPainterOffscreenRenderer(w, h, mode, (0.2, 0.8, 1.0), sensitivity, fps, path, **view_state)
+    total = int(np.ceil(r.duration * fps))
+    out = dict(audio=audio, sample_rate=sr, fps=fps, size=np.asarray(size), mode=np.asarray(mode),
+               sensitivity=np.float64(sensitivity), frames=np.asarray(frames),
+               view_state_json=np.asarray(__import__("json").dumps(view_state)))
+    keep = set(int(f) for f in frames)
+    pens_rgba = np.zeros((total, 16, 4), np.int64)      # glow pens of every frame in paint order, zero padded
+    pens_width = np.zeros((total, 16), np.int64)
+    n_pens = np.zeros(total, np.int64)
+    for i in range(total):
+        s, spec = r._read_frame(i / fps)
+        calls = r._view.render_frame_to_qimage(w, h, s, spec).calls
+        plus, glow_pens, glow_paths, hints = False, [], 0, []
+        for c in calls:
+            if c[0] == "setCompositionMode":
+                plus = c[1] == QPainter.CompositionMode_Plus
+            elif c[0] == "restore":
+                plus = False
+            elif plus and c[0] == "setPen":
+                glow_pens.append(c)
+                assert (c[3], c[4]) == ("RoundCap", "RoundJoin")
+            elif plus and c[0] == "drawPath":
+                glow_paths += 1
+            elif plus and c[0] == "setRenderHint":
+                hints.append(c[1:])
+        assert glow_paths == len(glow_pens)
+        n_pens[i] = len(glow_pens)
+        for k, c in enumerate(glow_pens):
+            pens_rgba[i, k], pens_width[i, k] = c[1], c[2]
+        if i in keep:
+            out[f"f{i}_calls"] = np.asarray([c[0] for c in calls])
+            dps = [c for c in calls if c[0] == "drawPath"]
+            out[f"f{i}_paths_equal"] = np.asarray([dps[k][1] == dps[k + 1][1] for k in range(len(dps) - 1)])
+            out[f"f{i}_path"] = _path_xy(dps[-1][1])
+            out[f"f{i}_comp_modes"] = np.asarray([c[1] for c in calls if c[0] == "setCompositionMode"], np.int64)
+    out.update(pens_rgba=pens_rgba, pens_width=pens_width, n_pens=n_pens)
+    np.savez_compressed(os.path.join(HERE, f"glow_{name}.npz"), **out)
+    print(f"glow_{name}: pens per frame {n_pens.min()}..{n_pens.max()}, widths {pens_width[0][:int(n_pens[0])].tolist()},",
+          f"alpha range {pens_rgba[:, 0, 3].min()}..{pens_rgba[:, 0, 3].max()};", list(out[f"f{frames[0]}_calls"]))
+
+
 # the case matrix of the FFmpeg argv fixture; tests/test_host_cpu.py replays it against aurora_amd.export.exporter
 FFMPEG_SYSTEMS = ["Linux", "Darwin", "Windows"]
 FFMPEG_ENCODER_SETS = [
@@ -501,6 +552,15 @@ def main():
         _install_stand_ins()
         sys.path.insert(0, REF)
         capture_ffmpeg_cmds()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "glow":           # adds the glow_* fixtures only
+        _install_stand_ins()
+        sys.path.insert(0, REF)
+        capture_glow("radial", "Spectrum - Radial", "pink", 24000, 48000, 60, (640, 368), dict(glow_enabled=True), [0, 3])
+        capture_glow("circular", "Waveform - Circular", "sweep", 24000, 48000, 60, (640, 368),
+                     dict(glow_enabled=True, glow_color="#FFFF4060", glow_radius=9, glow_strength=100,
+                          shadow_enabled=True, radial_fill_enabled=True, radial_fill_threshold=0.0), [0, 3],
+                     sensitivity=2.5)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "shadow":         # adds the shadow_* fixtures only
         _install_stand_ins()

@@ -368,7 +368,17 @@ def test_worker_end_to_end_raw_stream(eng, tmp_path, capsys):
                              shadow=ShadowConfig.from_view_state(vs)).render_device()).tobytes()
     assert raw.read_bytes() == want
     # unsupported decoration -> exit 1 with an error message, as the reference reports export failures (worker.py:77-79)
-    cfg["view_state"] = {"hip_device": 0, "glow_enabled": True}
+    # the glow keys through the worker ("Waveform - Circular")
+    from aurora_amd.engine import GlowConfig
+    vs = {"hip_device": 0, "glow_enabled": True, "glow_radius": 12, "glow_strength": 90}
+    cfg.update(mode="Waveform - Circular", view_state=vs)
+    cfgp.write_text(json.dumps(cfg))
+    assert worker.main(["worker.py", str(cfgp)]) == 0
+    capsys.readouterr()
+    want = _np(FramePipeline(eng, track, "Waveform - Circular", W, H,
+                             glow=GlowConfig.from_view_state(vs)).render_device()).tobytes()
+    assert raw.read_bytes() == want
+    cfg["view_state"] = {"hip_device": 0, "background_path": "bg.png"}
     cfgp.write_text(json.dumps(cfg))
     assert worker.main(["worker.py", str(cfgp)]) == 1
     assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["type"] == "error"
@@ -797,6 +807,98 @@ def test_shadow_decoration_raster_bit_exact(eng, mode, vs):
             for rv, a in zip(rings_all[f], alphas):
                 R.blend_solid(want, R.unpack_mask(R.polygon_mask(rv, W, H), W), R.BG, a)
         assert np.array_equal(frames[f], want), (mode, f, int(np.sum(frames[f] != want)))
+
+
+# ------------------------------------------------------------------ glow decoration (`_draw_glow_offscreen`)
+
+@pytest.mark.parametrize("mode,vs,size", [
+    ("Spectrum - Radial", dict(glow_enabled=True), (640, 368)),
+    ("Spectrum - Radial", dict(glow_enabled=True, glow_color="#FF40FF80", glow_radius=40, glow_strength=100,
+                               shadow_enabled=True, radial_fill_enabled=True, radial_fill_threshold=0.0,
+                               edge_waviness=50, feather_enabled=True), (640, 368)),
+    ("Waveform - Circular", dict(glow_enabled=True, glow_color="#FFFF4060", glow_radius=9, glow_strength=100,
+                                 shadow_enabled=True, radial_fill_enabled=True, radial_fill_threshold=0.0), (500, 282)),
+])
+def test_glow_decoration_raster_bit_exact(eng, mode, vs, size):
+    """Frames with the glow on == the oracle's layer-by-layer composite in the reference's painting order (fill, path
+    shadow, glow, stroke, envelope shadow, disc, rings); pens / order are pinned by tests/golden/glow_*.npz."""
+    from aurora_amd import synth
+    from aurora_amd.engine import FillConfig, GlowConfig, ShadowConfig
+    from aurora_amd.pipeline import FramePipeline
+    (W, H), sr, fps = size, 48000, 60
+    audio = synth.pink(4000, 2, seed=78) * 3.0           # loud enough for the alpha to move with the energy
+    track = eng.upload_track(audio, sr, fps)
+    fc, sh, gc = FillConfig.from_view_state(vs), ShadowConfig.from_view_state(vs), GlowConfig.from_view_state(vs)
+    radial = _radial_cfg(vs) if "Radial" in mode else None
+    pipe = FramePipeline(eng, track, mode, W, H, radial=radial, fill=fc, shadow=sh, glow=gc)
+    assert pipe.glow is not None
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    energy, pen = _np(sc.energy), _np(sc.pen_rgb)[:, :3]
+    fill_rgb = R.fill_colour_over_background(fc.rgba, fc.blend) if fc.enabled else None
+    dx, dy = sh.offset
+    rings_all = None
+    if radial is not None:
+        verts, env = eng.radial_vertices(pipe._radial_prep, an, sc, W, H, 0, an.n_frames)
+        verts, env = _np(verts), _np(env)
+        if radial.feather_enabled:
+            rings_all = _np(eng.feather_ring_vertices(pipe._radial_prep, an, sc, W, H, 0, an.n_frames))
+    else:
+        verts, env = _np(eng.wave_circular_vertices(an, sc, W, H, 0, an.n_frames, 0.0)), None
+    alphas = [max(10, 70 - 10 * k) for k in range(1, 7)]
+    lit = 0
+    for f in range(an.n_frames):
+        want = np.empty((H, W, 3), np.uint8)
+        want[:] = np.asarray(R.BG, np.uint8)
+        if fill_rgb is not None and energy[f] >= fc.threshold:
+            want[R.unpack_mask(R.polygon_mask(verts[f], W, H), W)] = np.asarray(fill_rgb, np.uint8)
+        if sh.active:
+            R.blend_solid(want, R.unpack_mask(R.stroke_mask_closed(verts[f], W, H, sh.half_width, dx, dy, True), W),
+                          (0, 0, 0), sh.alpha)
+        before = want.copy()
+        R.apply_glow(want, verts[f], float(energy[f]), np.ones((H, W), bool), W, H, gc.rgba, gc.radius, gc.strength,
+                     gc.layers)
+        lit += int(np.sum(want != before))
+        want[R.unpack_mask(R.stroke_mask_closed(verts[f], W, H), W)] = pen[f]
+        if env is not None:
+            if sh.active:
+                R.blend_solid(want, R.unpack_mask(R.stroke_mask_closed(env[f], W, H, sh.half_width, dx, dy, False), W),
+                              (0, 0, 0), sh.alpha)
+            want[R.unpack_mask(R.polygon_mask(env[f], W, H), W)] = np.asarray(R.DISC_RGB, np.uint8)
+        if rings_all is not None:
+            for rv, a in zip(rings_all[f], alphas):
+                R.blend_solid(want, R.unpack_mask(R.polygon_mask(rv, W, H), W), R.BG, a)
+        assert np.array_equal(frames[f], want), (mode, f, int(np.sum(frames[f] != want)))
+    assert lit > 1000 * an.n_frames
+
+
+def test_add_planes_saturation_and_odd_width(eng):
+    """aur_add_planes alone: 16 layers of random planes and colours that saturate, a width that is no multiple of 8
+    (byte path) and one that is (vector path), against numpy."""
+    import torch
+    from aurora_amd import _lib
+    from aurora_amd.engine import _ptr
+    rng = np.random.default_rng(5)
+    for W, H, K, F in ((1000, 40, 16, 3), (1024, 33, 5, 2), (72, 16, 1, 1)):
+        W32 = (W + 31) // 32
+        planes = rng.integers(0, 2**32, size=(K, F, H, W32), dtype=np.uint64).astype(np.uint32)
+        planes &= rng.integers(0, 2**32, size=planes.shape, dtype=np.uint64).astype(np.uint32)
+        planes[:, :, ::3] = 0
+        pm = rng.integers(0, 120, size=(F, K, 4), dtype=np.uint8)
+        pm[..., 3] = 0
+        frames = rng.integers(0, 256, size=(F, H, W, 3), dtype=np.uint8)
+        d_pl = torch.from_numpy(planes.view(np.int32)).to(eng.device)
+        d_pm = torch.from_numpy(pm).to(eng.device)
+        d_fr = torch.from_numpy(frames.copy()).to(eng.device)
+        _lib.check(eng.lib.aur_add_planes(eng.ctx.handle, _ptr(d_pl), K, _ptr(d_pm), F, W, H, _ptr(d_fr), eng.stream()),
+                   "aur_add_planes")
+        want = frames.astype(np.uint32)
+        for k in range(K):
+            for f in range(F):
+                m = R.unpack_mask(planes[k, f], W)
+                want[f][m] += pm[f, k, :3].astype(np.uint32)
+        want = np.minimum(want, 255).astype(np.uint8)
+        assert np.array_equal(_np(d_fr), want), (W, H, K)
 
 
 # ------------------------------------------------------------------ shadow of "Waveform - Linear" (rt_widget.py:915-930)

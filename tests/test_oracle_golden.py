@@ -317,3 +317,51 @@ def test_linear_waveform_shadow_matches_reference_calls():
         assert list(g[k + "_calls"]) == ['fillRect', 'setPen', 'save', 'translate', 'setPen', 'drawPath', 'restore',
                                          'setPen', 'drawPath', 'end']
         assert list(g[k + "_paths_equal"]) == [True] and list(g[k + "_path_lens"]) == [W, W]
+
+
+@pytest.mark.parametrize("fixture", ["glow_radial", "glow_circular"])
+def test_glow_decoration_matches_reference_calls(fixture):
+    """`_draw_glow_path` -> `_draw_glow_offscreen` (rt_widget.py:598-616, :634-653): the pens of EVERY frame (colour,
+    energy-dependent alpha, width), composition mode and call order, against the oracle's glow_pens and the host's
+    GlowConfig fed the oracle's energy."""
+    import json
+    from aurora_amd.engine import FillConfig, GlowConfig, ShadowConfig
+    g = load_golden(fixture)
+    vs = json.loads(str(g["view_state_json"]))
+    gc = GlowConfig.from_view_state(vs)
+    assert gc.active
+    ref = A.analyze_track(g["audio"], int(g["sample_rate"]), int(g["fps"]), sensitivity=float(g["sensitivity"]))
+    energy = ref["energy"]
+    table = gc.layer_table()
+    alpha = gc.layer_alpha(energy)
+    assert alpha.shape == (len(energy), len(table)) and len(energy) == len(g["n_pens"])
+    for f in range(len(energy)):
+        n = int(g["n_pens"][f])
+        want = [(int(w), tuple(int(v) for v in c)) for w, c in zip(g["pens_width"][f, :n], g["pens_rgba"][f, :n])]
+        pens = R.glow_pens(float(energy[f]), gc.rgba, gc.radius, gc.strength, gc.layers)
+        assert [(w, tuple(gc.rgba[:3]) + (a,)) for w, a in pens] == want, f                  # oracle
+        host = [(table[k][0], tuple(gc.rgba[:3]) + (int(alpha[f, k]),)) for k in range(len(table)) if alpha[f, k] > 0]
+        assert host == want, f                                                               # host side
+    assert len(set(g["pens_rgba"][:, 0, 3].tolist())) > 1          # the alpha does follow the energy in this fixture
+    radial = "Radial" in str(g["mode"])
+    for f in g["frames"]:
+        k = f"f{int(f)}"
+        calls = list(g[k + "_calls"])
+        n = int(g["n_pens"][int(f)])
+        glow = ['save', 'setRenderHint', 'setCompositionMode'] + ['setPen', 'drawPath'] * n + ['restore']
+        if radial:      # glow, stroke of the same path, disc
+            assert calls == ['fillRect', 'setPen'] + glow + ['drawPath', 'save', 'setRenderHint', 'setClipPath',
+                                                              'fillPath', 'restore', 'end']
+        else:           # fill, shadow, glow, stroke
+            assert FillConfig.from_view_state(vs).enabled and ShadowConfig.from_view_state(vs).active
+            assert calls == ['fillRect', 'setPen', 'save', 'fillPath', 'restore', 'save', 'translate', 'setPen',
+                             'drawPath', 'restore'] + glow + ['drawPath', 'end']
+        assert list(g[k + "_comp_modes"]) == [12]                   # QPainter.CompositionMode_Plus
+        assert all(g[k + "_paths_equal"])                           # every layer strokes the path of the final stroke
+
+
+def test_add_solid_saturates():
+    fr = np.array([[[13, 13, 18], [250, 100, 0]]], np.uint8)
+    R.add_solid(fr, np.array([[True, True]]), (255, 64, 96), 97)
+    # div255(255*97) = 97, div255(64*97) = 24, div255(96*97) = 37
+    assert fr.tolist() == [[[110, 37, 55], [255, 124, 37]]]

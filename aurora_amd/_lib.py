@@ -115,7 +115,7 @@ def _declare(lib):
     lib.aur_feather_ring_vertices.argtypes = [vp, vp, vp, vp, i32, C.POINTER(EnvelopeParams), vp, i32, i32, vp, vp]
     lib.aur_plane_exclude.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]
     lib.aur_blend_planes.argtypes = [vp, vp, i32, C.c_char_p, i32, i32, i32, vp, vp]
-    lib.aur_add_planes.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp]
+    lib.aur_add_planes.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.aur_wave_circular_vertices.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp]
     lib.aur_mask_stroke_closed.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.aur_rgb24_to_yuv420p.argtypes = [vp, vp, i32, i32, i32, vp, vp]

@@ -871,11 +871,14 @@ __global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __res
     const int word0 = blockIdx.x * 256 + wave * 64;         // first word of this wave
     if (word0 >= words) return;                             // wave-uniform
     const int mine = (word0 + lane < words) ? word0 + lane : words - 1;
-    uint32_t any = 0;
+    uint32_t any = 0, raw[KT];
+    // all loads first, unconditional (planes beyond K re-read plane K - 1): behind a branch, or with the LDS store of
+    // one value ahead of the next load, each load waits for the one before it
+#pragma unroll
+    for (int k = 0; k < KT; ++k) raw[k] = planes[((size_t)f * K + min(k, K - 1)) * words + mine];
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-        uint32_t v = 0;
-        if (k < K && word0 + lane < words) v = planes[((size_t)f * K + k) * words + mine];
+        const uint32_t v = (k >= K || word0 + lane >= words) ? 0u : raw[k];
         s_w[wave][k][lane] = v;
         any |= v;
     }
@@ -933,47 +936,71 @@ static void launch_blend(bool vec, dim3 grid, hipStream_t st, const uint32_t* pl
 // the sum).  Planes are layer-major, uint32 [K][F][H][W32], so that a layer is one aur_mask_stroke_path call.
 // One lane per 32-pixel word; lanes whose word has no bit in any layer (most of a frame) stop after the K loads.
 constexpr int kAddMaxK = 16;
-template <bool VEC>
+// One lane per quarter word (8 pixels): the four lanes of a word read the same plane words (one cache line, no extra HBM
+// traffic) and a lane whose 8 pixels have no bit in any layer (most of a frame) stops after the K loads.  The stroke and
+// disc planes that the reference paints afterwards are masked out here (excl_a per frame, excl_b per frame or static).
+template <bool VEC, int KT>
 __global__ __launch_bounds__(256) void add_planes_kernel(const uint32_t* __restrict__ planes, int K, size_t layer_stride,
-                                                         const uint32_t* __restrict__ pm, int W, int H, int W32,
-                                                         uint8_t* __restrict__ frames) {
+                                                         const uint32_t* __restrict__ pm,
+                                                         const uint32_t* __restrict__ excl_a,
+                                                         const uint32_t* __restrict__ excl_b, int excl_b_static, int W,
+                                                         int H, int W32, uint8_t* __restrict__ frames) {
     const int f = blockIdx.y;
     const int words = H * W32;
-    const int word = blockIdx.x * 256 + threadIdx.x;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int word = id >> 2, q = id & 3;
     if (word >= words) return;
-    uint32_t m[kAddMaxK], any = 0;
+    const size_t at = (size_t)f * words + word;
+    // every load is unconditional (layers beyond K re-read layer K - 1, a missing exclusion plane reads layer 0) so that
+    // all of them are in flight at once: behind `k < K` branches each load waited for the one before it
+    const uint32_t* pa = excl_a ? excl_a + at : planes + at;
+    const uint32_t* pb = excl_b ? excl_b + (excl_b_static ? (size_t)word : at) : planes + at;
+    uint32_t va = *pa, vb = *pb, raw[KT];
 #pragma unroll
-    for (int k = 0; k < kAddMaxK; ++k) {
-        m[k] = k < K ? planes[k * layer_stride + (size_t)f * words + word] : 0u;
+    for (int k = 0; k < KT; ++k) raw[k] = planes[(size_t)min(k, K - 1) * layer_stride + at];
+    if (!excl_a) va = 0;
+    if (!excl_b) vb = 0;
+    const uint32_t keep = (~(va | vb) >> (8 * q)) & 0xffu;
+    uint32_t m[KT], any = 0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        m[k] = k < K ? (raw[k] >> (8 * q)) & keep : 0u;
         any |= m[k];
     }
     if (any == 0) return;
-    uint32_t crb[kAddMaxK], cg[kAddMaxK];
+    uint32_t crb[KT], cg[KT];
 #pragma unroll
-    for (int k = 0; k < kAddMaxK; ++k) {
+    for (int k = 0; k < KT; ++k) {
         const uint32_t c = k < K ? pm[(size_t)f * K + k] : 0u;      // block-uniform
         crb[k] = c & 0x00ff00ffu;
         cg[k] = (c >> 8) & 0xffu;
     }
     const int row = word / W32, w = word - row * W32;
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t a8 = (any >> (8 * q)) & 0xffu;
-        if (a8 == 0) continue;
-        const int x0 = w * 32 + q * 8;
-        quarter_rmw<VEC>(a8, [&](int b, uint32_t& rb, uint32_t& g) {
-            uint32_t srb = rb, sg = g;                               // at most 255 + 16 * 255 per 16-bit half
+    const int x0 = w * 32 + q * 8;
+    quarter_rmw<VEC>(any, [&](int b, uint32_t& rb, uint32_t& g) {
+        uint32_t srb = rb, sg = g;                                   // at most 255 + 16 * 255 per 16-bit half
 #pragma unroll
-            for (int k = 0; k < kAddMaxK; ++k) {
-                const uint32_t on = 0u - ((m[k] >> (8 * q + b)) & 1u);
-                srb += crb[k] & on;
-                sg += cg[k] & on;
-            }
-            const uint32_t r = min(srb & 0xffffu, 255u), bl = min(srb >> 16, 255u);
-            rb = r | (bl << 16);
-            g = min(sg, 255u);
-        }, W, x0, frames + (((size_t)f * H + row) * W + x0) * 3);
-    }
+        for (int k = 0; k < KT; ++k) {
+            const uint32_t on = 0u - ((m[k] >> b) & 1u);
+            srb += crb[k] & on;
+            sg += cg[k] & on;
+        }
+        const uint32_t r = min(srb & 0xffffu, 255u), bl = min(srb >> 16, 255u);
+        rb = r | (bl << 16);
+        g = min(sg, 255u);
+    }, W, x0, frames + (((size_t)f * H + row) * W + x0) * 3);
+}
+
+template <int KT>
+static void launch_add(bool vec, dim3 grid, hipStream_t st, const uint32_t* planes, int K, size_t layer_stride,
+                       const uint32_t* pm, const uint32_t* ea, const uint32_t* eb, int eb_static, int W, int H, int W32,
+                       uint8_t* frames) {
+    if (vec)
+        hipLaunchKernelGGL((add_planes_kernel<true, KT>), grid, dim3(256), 0, st, planes, K, layer_stride, pm, ea, eb,
+                           eb_static, W, H, W32, frames);
+    else
+        hipLaunchKernelGGL((add_planes_kernel<false, KT>), grid, dim3(256), 0, st, planes, K, layer_stride, pm, ea, eb,
+                           eb_static, W, H, W32, frames);
 }
 
 extern "C" int aur_wave_linear_vertices(aur_ctx* ctx, const float* d_samples, const int32_t* d_col2samp,
@@ -1062,8 +1089,9 @@ extern "C" int aur_blend_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, c
     return AUR_OK;
 }
 
-extern "C" int aur_add_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t* d_pm_rgb, int n_frames,
-                             int W, int H, uint8_t* d_frames, void* stream) {
+extern "C" int aur_add_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t* d_pm_rgb,
+                             const uint32_t* d_excl_a, const uint32_t* d_excl_b, int excl_b_static, int n_frames, int W,
+                             int H, uint8_t* d_frames, void* stream) {
     int rc = aur_use_device(ctx);
     if (rc) return rc;
     AUR_REQUIRE(K >= 1 && K <= kAddMaxK, "aur_add_planes: K %d outside [1, %d]", K, kAddMaxK);
@@ -1074,15 +1102,13 @@ extern "C" int aur_add_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, con
     AUR_REQUIRE(((uintptr_t)d_pm_rgb & 3u) == 0, "aur_add_planes: colour table not 4-byte aligned");
     const int W32 = (W + 31) / 32;
     const size_t layer_stride = (size_t)n_frames * H * W32;
-    const dim3 grid((H * W32 + 255) / 256, n_frames);
+    const dim3 grid((4 * H * W32 + 255) / 256, n_frames);   // one lane per quarter word
     const bool vec = W % 8 == 0 && ((uintptr_t)d_frames & 7u) == 0;
     const uint32_t* pm = reinterpret_cast<const uint32_t*>(d_pm_rgb);
-    if (vec)
-        hipLaunchKernelGGL((add_planes_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, d_planes, K, layer_stride,
-                           pm, W, H, W32, d_frames);
-    else
-        hipLaunchKernelGGL((add_planes_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, d_planes, K,
-                           layer_stride, pm, W, H, W32, d_frames);
+    hipStream_t st = (hipStream_t)stream;
+    const int ebs = excl_b_static ? 1 : 0;
+    if (K <= 8) launch_add<8>(vec, grid, st, d_planes, K, layer_stride, pm, d_excl_a, d_excl_b, ebs, W, H, W32, d_frames);
+    else launch_add<kAddMaxK>(vec, grid, st, d_planes, K, layer_stride, pm, d_excl_a, d_excl_b, ebs, W, H, W32, d_frames);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -643,16 +643,19 @@ class HipExportEngine:
         h, st = self.ctx.handle, self.stream()
         table = glow.layer_table()
         K = len(table)
-        energy = sc.energy[first:first + count].cpu().numpy()
-        pm = torch.from_numpy(glow.layer_premultiplied(energy)).to(self.device)
+        # layer colours of the whole scan, once (12 B per frame and layer from the host-side expression)
+        key = (tuple(glow.rgba), glow.radius, glow.strength, glow.layers)
+        cache = getattr(sc, "_glow_pm", None)
+        if cache is None or cache[0] != key:
+            cache = (key, torch.from_numpy(glow.layer_premultiplied(sc.energy.cpu().numpy())).to(self.device))
+            sc._glow_pm = cache
+        pm = cache[1][first:first + count]
         planes = self.empty((K, count, H, W32), torch.int32)
         for k, (width, _) in enumerate(table):
             _lib.check(self.lib.aur_mask_stroke_path(h, _ptr(verts), int(verts.shape[1]), count, W, H, width / 2.0,
                                                      0.0, 0.0, 1, 1, _ptr(planes[k]), st), "aur_mask_stroke_path")
-            _lib.check(self.lib.aur_plane_exclude(h, _ptr(planes[k]), _ptr(excl_a), _ptr(excl_b),
-                                                  int(bool(excl_b_static)), None, count, W, H, st), "aur_plane_exclude")
-        _lib.check(self.lib.aur_add_planes(h, _ptr(planes), K, _ptr(pm), count, W, H, _ptr(frames), st),
-                   "aur_add_planes")
+        _lib.check(self.lib.aur_add_planes(h, _ptr(planes), K, _ptr(pm), _ptr(excl_a), _ptr(excl_b),
+                                           int(bool(excl_b_static)), count, W, H, _ptr(frames), st), "aur_add_planes")
         return frames
 
     # QColor(13, 13, 18) with alpha max(10, 70 - 10 k), k = 1..6 (rt_widget.py:1099, :1116)

@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--mode", default="Spectrum - Linear")
+    ap.add_argument("--glow", action="store_true", help="closed-path modes: add the glow decoration (7 additive strokes)")
     ap.add_argument("--batch", type=int, default=128, help="frames per raster launch (device slot size)")
     ap.add_argument("--cpu-frames", type=int, default=240, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--pcie-frames", type=int, default=1024, help="frames of the PCIe-inclusive leg (0 = skip)")
@@ -102,7 +103,7 @@ def main():
             dist.init_process_group(backend)
 
     from aurora_amd import _lib, sharding, synth
-    from aurora_amd.engine import RadialConfig, get_engine, mode_kind
+    from aurora_amd.engine import GlowConfig, RadialConfig, get_engine, mode_kind
     from aurora_amd.pipeline import FramePipeline, NullSink
 
     eng = get_engine(dev_index)
@@ -164,6 +165,11 @@ def main():
             if ev_fill is not None:
                 e1.record()
                 ev_fill.append((e0, e1, n))
+            if args.glow and planes_mode:
+                verts = (eng.radial_path_vertices(prep, sc, W, H, done, n) if radial is not None
+                         else eng.wave_circular_vertices(an, sc, W, H, done, n))
+                eng.apply_glow(GlowConfig(enabled=True), verts, sc, done, n, planes[0], planes[1], planes[2],
+                               dev_frames[s][:n])
             if feather is not None:
                 eng.feather_blend(prep, an, sc, W, H, done, n, dev_frames[s][:n], with_disc=True)
             done += n
@@ -248,7 +254,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 FFT / f32 magnitudes / u8 RGB24",
             "data": "synthetic",
             "config": {"workload": f"configs[4] unit: {args.seconds:.0f} s {sr} Hz stereo pink-noise track per GPU, "
-                                   f"{args.mode} {W}x{H}@{fps}, {F} frames per GPU per step, frames stay in HBM",
+                                   f"{args.mode}{' + glow' if args.glow else ''} {W}x{H}@{fps}, {F} frames per GPU per step, frames stay in HBM",
                        "frames_per_gpu": F, "batch_frames": B, "parallelism": f"time/track shards x{world}"},
             "stft_gbs": roof_stft["achieved"] if roof_stft else None,
             "roofline": roof, "roofline_stft": roof_stft, "cpu_baseline": cpu,

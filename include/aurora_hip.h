@@ -280,13 +280,16 @@ int aur_plane_exclude(aur_ctx* ctx, uint32_t* d_plane, const uint32_t* d_excl_a,
  * _offscreen_paint, exporter.py:118): before the closed path of "Spectrum - Radial" / "Waveform - Circular" is stroked,
  * it is stroked `layers` times with RoundCap / RoundJoin pens of width max(3, int(2 + radius (0.35 + 0.9 t))) in the glow
  * colour with alpha int(255 base_alpha intensity 0.55 (1 - t)^2), CompositionMode_Plus.  Layer planes come from
- * aur_mask_stroke_path(round_join = 1) and aur_plane_exclude (the stroke and the disc are painted afterwards, opaque);
- * aur_add_planes adds, for frame f and layer k, the premultiplied colour d_pm_rgb[f][k] = (div255(r a), div255(g a),
- * div255(b a), 0) (computed by the host side from the frame's energy) to every pixel of plane k, saturating each channel
- * at 255 (comp_func_Plus on an opaque destination; the reference's antialiased edge coverage is not reproduced).
+ * aur_mask_stroke_path(round_join = 1).  aur_add_planes adds, for frame f and layer k, the premultiplied colour
+ * d_pm_rgb[f][k] = (div255(r a), div255(g a), div255(b a), 0) (computed by the host side from the frame's energy) to every
+ * pixel of plane k that is in neither exclusion plane (d_excl_a [n_frames, H, W32]; d_excl_b per frame, or one plane for
+ * all frames when excl_b_static != 0; either may be NULL: the stroke and the disc, which the reference paints afterwards
+ * with opaque colours), saturating each channel at 255 (comp_func_Plus on an opaque destination; the reference's
+ * antialiased edge coverage is not reproduced).
  * d_planes: uint32 [K, n_frames, H, ceil(W/32)] (layer-major), K <= 16; d_pm_rgb: uint8 [n_frames, K, 4], 4-byte aligned. */
-int aur_add_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t* d_pm_rgb, int n_frames, int W, int H,
-                   uint8_t* d_frames, void* stream);
+int aur_add_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t* d_pm_rgb, const uint32_t* d_excl_a,
+                   const uint32_t* d_excl_b, int excl_b_static, int n_frames, int W, int H, uint8_t* d_frames,
+                   void* stream);
 
 /* RGB24 frames of "Spectrum - Radial" / "Waveform - Circular" (paint_frame, rt_widget.py:821-852): background
  * (13,13,18), stroke plane in the pen colour, disc plane in (30,30,40) on top (an all-zero static plane when the mode

@@ -890,12 +890,17 @@ def test_add_planes_saturation_and_odd_width(eng):
         d_pl = torch.from_numpy(planes.view(np.int32)).to(eng.device)
         d_pm = torch.from_numpy(pm).to(eng.device)
         d_fr = torch.from_numpy(frames.copy()).to(eng.device)
-        _lib.check(eng.lib.aur_add_planes(eng.ctx.handle, _ptr(d_pl), K, _ptr(d_pm), F, W, H, _ptr(d_fr), eng.stream()),
-                   "aur_add_planes")
+        excl_a = rng.integers(0, 2**32, size=(F, H, W32), dtype=np.uint64).astype(np.uint32)
+        excl_b = rng.integers(0, 2**32, size=(1, H, W32), dtype=np.uint64).astype(np.uint32)
+        excl_a &= rng.integers(0, 2**32, size=excl_a.shape, dtype=np.uint64).astype(np.uint32)
+        d_ea = torch.from_numpy(excl_a.view(np.int32)).to(eng.device) if K > 1 else None
+        d_eb = torch.from_numpy(excl_b.view(np.int32)).to(eng.device)
+        _lib.check(eng.lib.aur_add_planes(eng.ctx.handle, _ptr(d_pl), K, _ptr(d_pm), _ptr(d_ea), _ptr(d_eb), 1, F, W, H,
+                                          _ptr(d_fr), eng.stream()), "aur_add_planes")
         want = frames.astype(np.uint32)
         for k in range(K):
             for f in range(F):
-                m = R.unpack_mask(planes[k, f], W)
+                m = R.unpack_mask(planes[k, f] & ~excl_b[0] & ~(excl_a[f] if K > 1 else np.uint32(0)), W)
                 want[f][m] += pm[f, k, :3].astype(np.uint32)
         want = np.minimum(want, 255).astype(np.uint8)
         assert np.array_equal(_np(d_fr), want), (W, H, K)

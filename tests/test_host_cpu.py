@@ -271,7 +271,7 @@ def test_new_entry_points_reject_bad_arguments_without_gpu():
     # every call fails on the null context before touching a device
     assert lib.aur_rgb24_to_yuv420p(None, None, 1, 64, 64, None, None) != 0
     assert lib.aur_blend_planes(None, None, 6, b"\0" * 24, 1, 64, 64, None, None) != 0
-    assert lib.aur_add_planes(None, None, 7, None, 1, 64, 64, None, None) != 0
+    assert lib.aur_add_planes(None, None, 7, None, None, None, 0, 1, 64, 64, None, None) != 0
     assert lib.aur_wave_circular_vertices(None, None, None, 1, None, 64, 64, None, None) != 0
     assert lib.aur_feather_ring_vertices(None, None, None, None, 1, None, None, 64, 64, None, None) != 0
     assert b"null" in lib.aur_last_error()

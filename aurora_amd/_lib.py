@@ -142,6 +142,9 @@ def load():
                 raise AuroraHipError(
                     f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
                     "aurora_amd has no CPU fallback")
+            # torch first: its bundled HIP/HSA runtime must be the one this library binds to.  Loaded the other
+            # way round the process holds two HSA runtimes and the second finds no device (hipGetDeviceCount fails).
+            import torch  # noqa: F401
             lib = C.CDLL(LIB_PATH)
             missing = [s for s in SYMBOLS if not hasattr(lib, s)]
             if missing:

@@ -248,7 +248,7 @@ def main():
     if rank == 0:
         value = world * F * args.steps / dt
         out = {
-            "metric": "exported frames/sec (whole node) 4K60 spectrum mode; STFT GB/s",
+            "metric": "exported frames/sec (whole node) 4K60 spectrum mode at 1/2/4/8 GPUs; STFT GB/s",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 FFT / f32 magnitudes / u8 RGB24",

@@ -64,3 +64,19 @@ static inline int aur_use_device(aur_ctx* ctx) {
     AUR_CHECK_HIP(hipSetDevice(ctx->device));
     return AUR_OK;
 }
+
+// Frame stores of the fill kernels.  Finished frames are written once and not read again by the kernel that writes
+// them, so they are stored non-temporally (global_store_dwordx4 ... nt): measured on MI355X the linear fill goes from
+// 6.46 to 6.85 TB/s (profiles/r01_fill_nt.txt).  -DAUR_STREAM_STORES=0 builds the plain-store variant for A/B runs.
+#ifndef AUR_STREAM_STORES
+#define AUR_STREAM_STORES 1
+#endif
+__device__ __forceinline__ void aur_store_frame16(uint4* p, const uint4& v) {
+#if AUR_STREAM_STORES
+    typedef unsigned int aur_u32x4 __attribute__((ext_vector_type(4)));
+    const aur_u32x4 ov = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(ov, reinterpret_cast<aur_u32x4*>(p));
+#else
+    *p = v;
+#endif
+}

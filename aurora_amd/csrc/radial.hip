@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void raster_fill_planes_kernel(const uint32_t*
     uint4* dst = frames + ((long)f * H + row0) * (long)nu4 + i;
     if (!busy) {
         for (int row = row0; row < row1; ++row) {
-            *dst = bgv;
+            aur_store_frame16(dst, bgv);
             dst += nu4;
         }
         return;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void raster_fill_planes_kernel(const uint32_t*
                 P[c] = ((db >> c) & 1u) ? kDisc24 : (((sb >> c) & 1u) ? pen : kBg24);   // disc is painted last
             o = pack_rgb16(P, ph);
         }
-        *dst = o;
+        aur_store_frame16(dst, o);
         dst += nu4;
     }
 }

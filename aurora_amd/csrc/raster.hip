@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void raster_fill_lin_kernel(const uint32_t* __
         }
         o = pack_rgb16(P, ph);
     }
-    frames[g] = o;
+    aur_store_frame16(frames + g, o);
 }
 
 int check_raster_dims(const char* who, int n_frames, int W, int H) {

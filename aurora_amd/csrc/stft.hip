@@ -33,6 +33,13 @@
 // Contraction is disabled for the whole library (-ffp-contract=off); fma is used explicitly where wanted.
 #include "common.h"
 
+// Spectrum stores: plain by default (-DAUR_STFT_NT=1 builds the non-temporal variant for A/B runs).
+#if AUR_STFT_NT
+#define AUR_STFT_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define AUR_STFT_ST(ptr, val) (*(ptr) = (val))
+#endif
+
 #include <type_traits>
 
 namespace {
@@ -478,11 +485,11 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
             if (j == 1) lg1 = l.x;
             if (STORE_LOG) {
                 if (p == 2 || p == 3) {
-                    out_a2[64 * j] = l.x;         // bin off2 + 64 j
-                    out_b2[-64 * j] = l.y;
+                    AUR_STFT_ST(out_a2 + 64 * j, l.x);         // bin off2 + 64 j
+                    AUR_STFT_ST(out_b2 - 64 * j, l.y);
                 } else {
-                    out_a[64 * j] = l.x;          // bin lane + 64 j
-                    out_b[-64 * j] = l.y;         // bin 1024 - lane - 64 j
+                    AUR_STFT_ST(out_a + 64 * j, l.x);          // bin lane + 64 j
+                    AUR_STFT_ST(out_b - 64 * j, l.y);          // bin 1024 - lane - 64 j
                 }
             }
         }

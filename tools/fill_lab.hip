@@ -1,5 +1,5 @@
 // Store-pattern laboratory for the frame fill (GPU box):  which shapes of a pure 16-byte-per-lane fill reach the
-// HBM write ceiling on MI355X?  Build: hipcc -O3 --offload-arch=gfx950 tools/fill_lab.hip -o tools/fill_lab
+// HBM write ceiling on MI355X?  Build: hipcc -O3 --offload-arch=gfx950 [-DLAB_NT=1] tools/fill_lab.hip -o tools/fill_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +23,15 @@ __global__ __launch_bounds__(T) void lin_kernel(uint4* __restrict__ p, long npie
     for (int r = 0; r < R; ++r) {
         long piece = strided ? (long)blockIdx.x + (long)r * gridDim.x : (long)blockIdx.x * R + r;
         piece = (piece & ~7L) | ((piece + rot) & 7L);
-        if (piece < npieces) p[piece * T + threadIdx.x] = val;
+        if (piece < npieces) {
+#if LAB_NT   // -DLAB_NT=1: non-temporal stores (the shipped fill kernels' store type)
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 ov = {val.x, val.y, val.z, val.w};
+            __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(p + piece * T + threadIdx.x));
+#else
+            p[piece * T + threadIdx.x] = val;
+#endif
+        }
     }
 }
 

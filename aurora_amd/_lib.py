@@ -21,7 +21,7 @@ SYMBOLS = (
     "aur_version", "aur_last_error", "aur_device_count", "aur_create", "aur_destroy", "aur_get_window",
     "aur_stft_frames", "aur_stft_buffer", "aur_log1p_f32", "aur_scan_frames",
     "aur_spans_spectrum_linear", "aur_spans_particles", "aur_spans_waveform_linear", "aur_raster_spans",
-    "aur_raster_work_bytes", "aur_span_summary", "aur_raster_spans_ws",
+    "aur_raster_work_bytes", "aur_span_summary", "aur_raster_spans_ws", "aur_raster_spans_static",
     "aur_radial_stage1", "aur_radial_ema", "aur_radial_vertices", "aur_envelope_vertices",
     "aur_feather_ring_vertices", "aur_blend_planes", "aur_add_planes", "aur_plane_exclude", "aur_wave_circular_vertices", "aur_mask_stroke_closed", "aur_mask_stroke_path", "aur_wave_linear_vertices", "aur_mask_polygon", "aur_raster_planes",
     "aur_rgb24_to_yuv420p",
@@ -30,6 +30,7 @@ SYMBOLS = (
 
 K_SPECTRUM, K_PARTICLES, K_WAVEFORM = 2, 2, 5
 FFT_SIZE, BLOCK, NBINS = 2048, 1024, 1025
+STATIC_WORK_BYTES = 3 * 1024 * 1024     # AUR_STATIC_WORK_BYTES
 
 
 class AuroraHipError(RuntimeError):
@@ -107,6 +108,7 @@ def _declare(lib):
     lib.aur_raster_work_bytes.argtypes = [i32, i32, C.POINTER(C.c_size_t)]
     lib.aur_span_summary.argtypes = [vp, vp, i32, i32, i32, i32, vp, C.c_size_t, vp]
     lib.aur_raster_spans_ws.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp, C.c_size_t, i32, vp]
+    lib.aur_raster_spans_static.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp]
     f64 = C.c_double
     lib.aur_radial_stage1.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp]
     lib.aur_radial_ema.argtypes = [vp, vp, i32, i32, f64, i32, vp, vp]

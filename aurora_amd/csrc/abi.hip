@@ -95,6 +95,12 @@ extern "C" int aur_create(int device, aur_ctx** out) {
         free(ctx);
         return AUR_EHIP;
     }
+    if (int rc = aur_raster_static_init(ctx)) {
+        (void)hipFree(ctx->d_window);
+        (void)hipFree(ctx->d_twid);
+        free(ctx);
+        return rc;
+    }
     *out = ctx;
     return AUR_OK;
 }

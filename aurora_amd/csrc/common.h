@@ -34,7 +34,11 @@ struct aur_ctx {
     int fill_nt;           // AUR_FILL_NT=1: non-temporal frame stores
     int fill_mode;         // AUR_FILL_MODE=1: aur_raster_spans_ws / aur_raster_planes use the row-tile kernels (A/B runs)
     int stft_fpw;          // AUR_STFT_FPW: frames per wave of the STFT kernel
+    void* d_static_work;   // this device's address of raster.hip's file-scope work area (aur_raster_spans_static)
 };
+
+// raster.hip: resolves the device address of the static work area for ctx->device (which must be current)
+int aur_raster_static_init(aur_ctx* ctx);
 
 void aur_set_error(const char* fmt, ...);
 

@@ -644,6 +644,43 @@ extern "C" int aur_raster_spans_ws(aur_ctx* ctx, const uint32_t* d_spans, int K,
     return AUR_OK;
 }
 
+// ---- allocation-free variant of aur_raster_spans_ws ------------------------------------------------------------------
+//
+// The work area of the linear fill (column summaries + merged intervals) lives in a file-scope device array instead of
+// caller memory, for callers that cannot allocate (HIP graph capture, serving loops).  Every GPU the library runs on
+// holds its own copy of the array at its own address: the address is resolved once per device in aur_create
+// (aur_raster_static_init, with that device current) and kept in the context; host code never uses the array's name for
+// anything but that look-up.
+static __device__ __align__(256) unsigned char scratch[AUR_STATIC_WORK_BYTES];
+
+int aur_raster_static_init(aur_ctx* ctx) {
+    void* p = nullptr;
+    AUR_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));      // the context's device is current (aur_create)
+    AUR_REQUIRE(p != nullptr && ((uintptr_t)p & 255u) == 0, "aur_create: static work area unresolved or misaligned");
+    ctx->d_static_work = p;
+    return AUR_OK;
+}
+
+extern "C" int aur_raster_spans_static(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb,
+                                       int n_frames, int W, int H, uint8_t* d_frames, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_raster_dims("aur_raster_spans_static", n_frames, W, H))) return rc;
+    AUR_REQUIRE(ctx->d_static_work != nullptr, "aur_raster_spans_static: static work area not initialised");
+    if (ctx->fill_mode == 1 || !raster_lin_ok(n_frames, W, H, d_frames))      // shapes of the row-tile fill: no work area
+        return aur_raster_spans(ctx, d_spans, K, d_pen_rgb, n_frames, W, H, d_frames, stream);
+    const size_t need = raster_work_bytes(n_frames, W);
+    AUR_REQUIRE(need <= (size_t)AUR_STATIC_WORK_BYTES,
+                "aur_raster_spans_static: %d frames of width %d need a work area of %zu bytes, the static one holds %d "
+                "(split the batch: at most %d frames of this width per call)",
+                n_frames, W, need, AUR_STATIC_WORK_BYTES,
+                (int)((size_t)AUR_STATIC_WORK_BYTES / raster_work_bytes(1, W)));
+    // the summary kernel rewrites every element the fill reads for this shape (summaries of all n_frames * nu4 columns,
+    // merged intervals of all n_frames * W pixel columns), so nothing of the previous call's contents is ever read
+    return aur_raster_spans_ws(ctx, d_spans, K, d_pen_rgb, n_frames, W, H, d_frames, ctx->d_static_work,
+                               (size_t)AUR_STATIC_WORK_BYTES, 0, stream);
+}
+
 extern "C" int aur_raster_spans(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb, int n_frames,
                                 int W, int H, uint8_t* d_frames, void* stream) {
     int rc = aur_use_device(ctx);

@@ -172,6 +172,18 @@ int aur_raster_spans_ws(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint
                         int n_frames, int W, int H, uint8_t* d_frames, void* d_work, size_t work_bytes, int work_ready,
                         void* stream);
 
+/* aur_raster_spans_ws without a work-area argument and without any allocation.  No counterpart in the reference: it is for
+ * callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  The work area is a file-scope device array of AUR_STATIC_WORK_BYTES inside the library (one copy per GPU,
+ * held until the process ends); a batch whose aur_raster_work_bytes(n_frames, W) exceeds it is rejected with AUR_EINVAL
+ * (3840 wide: at most 148 frames per call; 1920: 297; 1280: 446).  Shapes the linear fill does not take (see
+ * aur_raster_spans_ws) go to aur_raster_spans, which needs no work area.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (different streams, threads or contexts) race; calls on one stream are ordered and safe.
+ * Results are byte-identical to aur_raster_spans_ws / aur_raster_spans. */
+#define AUR_STATIC_WORK_BYTES (3 * 1024 * 1024)
+int aur_raster_spans_static(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb /*[F,4]*/,
+                            int n_frames, int W, int H, uint8_t* d_frames, void* stream);
+
 /* ---- "Spectrum - Radial": radial path, centre-disc envelope, bit planes ------------------------------------ */
 
 /* Stage 1 of the radial spectrum (rt_widget.py:938-951): spectrum[:80] / max (float32) -> optional mirror

@@ -48,6 +48,11 @@ static void build_tables(float* window, double* tw) {
             tw[AUR_TW_P1 + 2 * ((k - 1) * 64 + l)] = cos(a);
             tw[AUR_TW_P1 + 2 * ((k - 1) * 64 + l) + 1] = sin(a);
         }
+    for (int i = 0; i < AUR_LG_ENTRIES; ++i) {
+        const double inv = 1.0 / (1.0 + (double)i / 128.0);
+        tw[AUR_TW_LG + 2 * i] = inv;
+        tw[AUR_TW_LG + 2 * i + 1] = (i == 0) ? 0.0 : (double)(-logl((long double)inv));
+    }
     for (int r = 0; r < 4; ++r)
         for (int q = 0; q < 16; ++q) {
             const double a = -two_pi * (double)(r * q) / 64.0;

@@ -15,13 +15,17 @@
 //     [AUR_TW_W2 ..)  tw2[r][q] = W64^(r*q)            r < 4, q < 16   pass-2 twiddles
 //     [AUR_TW_WS ..)  ws[l]     = wu[l] for l > 0, 0.5 * W2048^128 for l = 0   unpack base of lane 0's shifted pairs
 //     [AUR_TW_P1 ..)  p1[k-1][l] = W1024^(l*k)         k = 1..15, l < 64   pass-1 twiddles
+//     [AUR_TW_LG ..)  lg[i]     = (1 / c_i, -log(1 / c_i)), c_i = 1 + i / 128, i <= 128: table of the correctly rounded
+//                                 log1p of the displayed bins (stft.hip: log1p_cr); not complex values
 //   with W_N = exp(-2 pi i / N).
 #define AUR_TW_W1      0
 #define AUR_TW_WU      128
 #define AUR_TW_W2      256
 #define AUR_TW_WS      384
 #define AUR_TW_P1      512
-#define AUR_TW_DOUBLES (512 + 15 * 128)
+#define AUR_TW_LG      (512 + 15 * 128)
+#define AUR_LG_ENTRIES 129
+#define AUR_TW_DOUBLES (AUR_TW_LG + 2 * AUR_LG_ENTRIES)
 
 struct aur_ctx {
     int device;

@@ -63,7 +63,8 @@ constexpr int kLdsWinBytes = AUR_FFT_SIZE * 4;   // float32 window
 constexpr int kTw2Stride = 17;                   // complex doubles per W64 row (16 + 1 pad: rows on distinct banks)
 constexpr int kLdsTw2Bytes = 4 * kTw2Stride * 16;   // W64^(r q), complex double
 constexpr int kLdsTw1Bytes = 15 * 64 * 16;          // W1024^(l k1), complex double [k1 - 1][l]
-constexpr int kLdsTabBytes = kLdsWinBytes + kLdsTw2Bytes + kLdsTw1Bytes;
+constexpr int kLdsLgBytes = ((AUR_LG_ENTRIES * 16 + 63) / 64) * 64;   // log table of log1p_cr: (1 / c_i, log c_i)
+constexpr int kLdsTabBytes = kLdsWinBytes + kLdsTw2Bytes + kLdsTw1Bytes + kLdsLgBytes;
 #ifndef AUR_STFT_PMAG_LDS
 #define AUR_STFT_PMAG_LDS 0
 #endif
@@ -244,6 +245,7 @@ struct Tables {
     cd wus;              // the same, except lane 0: 0.5 * W2048^128 (its pairs (640,384), (896,128); see unpack_mag)
     int b0, b1;          // exchange-2 positions of the partner groups: Z[b + 256 s], s < 4
     int off2;            // first bin of the slots (ql = 0, s >= 2): lane, except lane 0: 128
+    const double2* lg;   // LDS: (1 / c_i, log c_i), c_i = 1 + i / 128, i <= 128 (log1p_cr)
 };
 
 // Stages the window and the W64 table into LDS (whole workgroup), loads the per-lane twiddle bases.  Ends with
@@ -262,6 +264,10 @@ __device__ __forceinline__ Tables stage_tables(const float* __restrict__ window,
     const double2* t1src = reinterpret_cast<const double2*>(twid + AUR_TW_P1);
     for (int i = threadIdx.x; i < 15 * 64; i += blockDim.x) t1[i] = t1src[i];
     t.tw1 = reinterpret_cast<const cd*>(t1) + lane;
+    double2* lg = reinterpret_cast<double2*>(smem + kLdsWinBytes + kLdsTw2Bytes + kLdsTw1Bytes);
+    const double2* lgsrc = reinterpret_cast<const double2*>(twid + AUR_TW_LG);
+    for (int i = threadIdx.x; i < AUR_LG_ENTRIES; i += blockDim.x) lg[i] = lgsrc[i];
+    t.lg = lg;
     t.wuh = cd{twid[AUR_TW_WU + 2 * lane], twid[AUR_TW_WU + 2 * lane + 1]};
     t.wus = cd{twid[AUR_TW_WS + 2 * lane], twid[AUR_TW_WS + 2 * lane + 1]};
     t.b0 = (lane == 0) ? 128 : 256 - lane;
@@ -383,6 +389,46 @@ __device__ __forceinline__ float log1p_pos(float x) {
     return fmaf(c, fmaxf(2.0f - u, 0.0f), __builtin_amdgcn_logf(u) * 0.693147180559945309f);
 }
 
+// ---- the displayed bins (k < 128; the export only draws spectrum[:80], rt_widget.py:935) in the reference's own chain ----
+//
+// A bar top is int(v * (h - 10) * ...) (rt_widget.py:986) and a particle row int(h / 2 + (v - 0.5) * h * 0.6) (:997), so a
+// last-ulp difference in log1p|X| moves them by a row in a fraction of the frames.  For bins < 128 the magnitude is therefore
+// computed the way numpy computes np.abs of the complex64 spectrum (audio/analysis.py:26) on the x86 hosts the fixtures
+// come from (numpy 2.x, AVX2 / AVX-512 + FMA3 dispatch of loops_unary_complex): round re, im to float32, then in float32
+//   |z| = max * sqrt(fma(d, d, 1)),  d = min / max,  max = max(|re|, |im|), min = min(|re|, |im|)
+// with IEEE division and square root -- bit-identical to np.abs(complex64) on 2 000 000 random values
+// (tests/test_host_cpu.py::test_numpy_cabs_formula).  The other bins keep mag_from_sq (flux only needs rtol 1e-4).
+__device__ __forceinline__ float cabs_c64(double re_d, double im_d) {
+    const float a = fabsf((float)re_d), b = fabsf((float)im_d);      // astype(complex64)
+    const float mx = fmaxf(a, b), mn = fminf(a, b);
+    const float d = mx > 0.0f ? mn / mx : 0.0f;                      // correctly rounded (no fast-math on this library)
+    return mx * __builtin_sqrtf(fmaf(d, d, 1.0f));
+}
+
+// Correctly rounded log1p of a float32 x >= 0 (np.log1p at audio/analysis.py:33 is within 1-2 ulp of this: numpy's
+// AVX-512 build calls SVML, whose rounding cannot be reproduced; 92.3 % of its results are the correctly rounded value).
+// float64: u = 1 + x is exact for x >= 2^-29; u = 2^e m, m in [1, 2); c = nearest multiple of 1/128 to m;
+// log u = e ln2 + log c + log1p(r), r = m / c - 1, |r| <= 2^-8 (degree-5 series: 2^-48 / 6 absolute); c = 1 gives
+// log c = 0 exactly, so results next to 0 keep their relative accuracy.  Below 2^-20: x - x^2 / 2.
+__device__ __forceinline__ float log1p_cr(float x, const double2* __restrict__ lg) {
+    const double xd = (double)x;
+    const double u = 1.0 + xd;
+    const unsigned long long ub = (unsigned long long)__double_as_longlong(u);
+    const unsigned hi = (unsigned)(ub >> 32);
+    const int e = (int)(hi >> 20) - 1023;
+    const unsigned i = (((hi >> 12) & 0xffu) + 1u) >> 1;             // 0 .. 128
+    const double m = __longlong_as_double((long long)((ub & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL));
+    const double2 t = lg[i];
+    const double r = fma(m, t.x, -1.0);
+    double p = fma(r, 0.2, -0.25);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    p = fma(r * r, p, r);
+    const double big = fma((double)e, 0.693147180559945309417, t.y) + p;
+    const double small = fma(-0.5 * xd, xd, xd);
+    return (float)(x < 9.5367431640625e-7f ? small : big);
+}
+
 // W32^j = exp(-2 pi i j / 32) for j = 1, 5
 constexpr double kW32re1 = 0.98078528040323044913, kW32im1 = -0.19509032201612826785;
 constexpr double kW32re5 = 0.55557023301960222474, kW32im5 = -0.83146961230254523708;
@@ -477,10 +523,11 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
         const double ty = fma(th[p].x, oy, th[p].y * ox);
         const double ar = fma(0.5, ex, tx), ai = fma(0.5, ey, ty);
         const double br = fma(0.5, ex, -tx), bi = fma(0.5, ey, -ty);
-        const v2f m = {mag_from_sq(fma(ar, ar, ai * ai)), mag_from_sq(fma(br, br, bi * bi))};
+        // j < 2: bin kA = lane + 64 j is one of the displayed bins: the reference's own magnitude / log1p chain
+        const v2f m = {j < 2 ? cabs_c64(ar, ai) : mag_from_sq(fma(ar, ar, ai * ai)), mag_from_sq(fma(br, br, bi * bi))};
         fl2 += __builtin_elementwise_max(m - pm.swap(p, m), (v2f)(0.0f));
         if (EMIT) {
-            const v2f l = log1p_pos2(m);
+            const v2f l = j < 2 ? v2f{log1p_cr(m.x, T.lg), log1p_pos(m.y)} : log1p_pos2(m);
             if (j == 0) lg0 = l.x;
             if (j == 1) lg1 = l.x;
             if (STORE_LOG) {

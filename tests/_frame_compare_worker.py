@@ -1,0 +1,23 @@
+"""Worker side of tests/test_gpu_e2e_parity.py: renders one frame with the ORACLE fed the oracle's own analysis values and
+compares it with the GPU frame parked in shared memory.  Runs in spawned CPU processes (numpy + oracle only, no torch)."""
+import numpy as np
+
+
+def compare_frame(task):
+    """-> (pixels that differ, pixels that differ by more than 1 LSB in a channel, PSNR in dB)."""
+    from multiprocessing import shared_memory
+    from oracle import raster_ref as R
+    shm_name, offset, mode, samples, spectrum, energy, pen, W, H = task
+    shm = shared_memory.SharedMemory(name=shm_name)
+    try:
+        got = np.ndarray((H, W, 3), dtype=np.uint8, buffer=shm.buf, offset=offset)
+        want = R.render_frame(mode, samples, spectrum, energy, pen, W, H)
+        if np.array_equal(got, want):
+            res = (0, 0, float("inf"))
+        else:
+            d = np.abs(got.astype(np.int16) - want.astype(np.int16)).max(axis=2)
+            res = (int(np.count_nonzero(d)), int(np.count_nonzero(d > 1)), float(R.psnr(got, want)))
+        del got
+        return res
+    finally:
+        shm.close()

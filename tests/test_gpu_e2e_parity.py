@@ -1,0 +1,132 @@
+"""End-to-end frame parity at FULL size: GPU audio -> GPU spectrum -> GPU frames against the oracle rasteriser fed the
+ORACLE'S OWN spectrum (not the GPU's), for BASELINE.json configs[1], [2], [3] and the 4K headline mode.
+
+What can differ: the displayed bins go through ``int(v * (h - 10) * ...)`` (rt_widget.py:986) and
+``int(h / 2 + (v - 0.5) * h * 0.6)`` (:997), so a last-ulp difference in ``log1p|X|`` moves a bar top or a particle by one
+row in a small fraction of frames.  The test counts those frames over >= 2000 frames sampled evenly from the 4 minute
+track, prints the rate (recorded in DESIGN.md 2) and bounds it.  The waveform mode depends on samples and energy only,
+which are bit-exact, so its frames must be identical.
+"""
+import multiprocessing as mp
+import os
+from multiprocessing import shared_memory
+
+import numpy as np
+import pytest
+
+from oracle import analysis_ref as A
+
+pytestmark = pytest.mark.gpu
+
+N_SAMPLED = 2000
+BATCH = 16
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from aurora_amd.engine import get_engine
+    return get_engine(0)
+
+
+@pytest.fixture(scope="module")
+def track4min(eng):
+    from aurora_amd import synth
+    sr, fps = 48000, 60
+    audio = synth.pink_device(sr * 240, 2, 1234, eng.device)
+    track = eng.make_track(audio, sr, fps)
+    an = eng.analyze(track, want_samples=True)
+    sc = eng.scan(an)
+    ref = A.analyze_track(audio.cpu().numpy(), sr, fps)            # the oracle's own analysis of the same samples
+    pen, _ = A.amp_to_color_track(ref["energy"])
+    return track, an, sc, ref, pen
+
+
+@pytest.fixture(scope="module")
+def pool():
+    import _frame_compare_worker  # noqa: F401  (tests/ is on sys.path; spawned workers import it by name)
+    ctx = mp.get_context("spawn")                                  # never fork a process that has initialised the GPU
+    with ctx.Pool(min(8, max(2, (os.cpu_count() or 2) // 2))) as p:
+        yield p
+
+
+# measured on MI355X: frames with any differing pixel / frames compared
+MAX_RATE = {"Spectrum - Linear": 0.004, "Particles": 0.004, "Waveform - Linear": 0.0}
+
+
+@pytest.mark.parametrize("mode,size", [("Spectrum - Linear", (1920, 1080)), ("Waveform - Linear", (3840, 2160)),
+                                       ("Particles", (1920, 1080)), ("Spectrum - Linear", (3840, 2160))])
+def test_frames_vs_oracle_own_spectrum(eng, track4min, pool, mode, size):
+    import torch
+    from _frame_compare_worker import compare_frame
+    track, an, sc, ref, pen = track4min
+    W, H = size
+    F = track.total_frames
+    picks = np.unique(np.linspace(0, F - 1, N_SAMPLED).astype(np.int64))
+    fb = W * H * 3
+    shms = [shared_memory.SharedMemory(create=True, size=BATCH * fb) for _ in range(2)]
+    try:
+        views = [np.ndarray((BATCH, H, W, 3), dtype=np.uint8, buffer=s.buf) for s in shms]
+        dev = eng.empty((BATCH, H, W, 3), torch.uint8)
+        pending, results = None, []
+        for b0 in range(0, len(picks), BATCH):
+            group = picks[b0:b0 + BATCH]
+            half = (b0 // BATCH) % 2
+            for j, f in enumerate(group):
+                eng.render(mode, an, sc, W, H, int(f), 1, out=dev[j:j + 1])
+            if pending is not None and half == pending[1]:
+                raise AssertionError("double buffering out of step")
+            host = dev[:len(group)].cpu().numpy()
+            # the half being overwritten was compared two batches ago (its map_async result has been collected)
+            views[half][:len(group)] = host
+            tasks = [(shms[half].name, j * fb, mode, ref["samples"][f], ref["logspec"][f], float(ref["energy"][f]),
+                      pen[f], W, H) for j, f in enumerate(group)]
+            if pending is not None:
+                results.extend(pending[0].get(timeout=300))
+            pending = (pool.map_async(compare_frame, tasks), half)
+        results.extend(pending[0].get(timeout=300))
+        del views
+    finally:
+        for s in shms:
+            s.close()
+            s.unlink()
+    assert len(results) == len(picks)
+    ndiff = np.array([r[0] for r in results])
+    nbad = np.array([r[1] for r in results])
+    ps = np.array([r[2] for r in results])
+    flipped = int(np.count_nonzero(ndiff))
+    rate = flipped / len(picks)
+    print(f"\n{mode} {W}x{H}: {flipped} of {len(picks)} sampled frames differ from the oracle's own export "
+          f"(rate {rate:.5f}); worst frame: {int(ndiff.max())} pixels differ, {int(nbad.max())} by more than 1 LSB, "
+          f"min PSNR {ps.min():.1f} dB")
+    assert ps.min() >= 50.0
+    # a flip moves one bar top (2 px wide) or one particle (2x2 px, leaves 2 and enters 2) by a row
+    assert nbad.max() <= 8
+    assert rate <= MAX_RATE[mode], rate
+
+
+def _ulps(a, b):
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+def test_displayed_bins_follow_the_reference_chain(eng, track4min):
+    """log1p|X| of the bins the export draws (spectrum[:80], rt_widget.py:935): the magnitude is numpy's own float32
+    complex-abs formula on the complex64-rounded spectrum (bit-exact), the log1p is correctly rounded where numpy's SVML
+    routine is within 1-2 ulp of that; measured: >= 90 % of the values bit-equal to the oracle, none off by more than 2 ulp."""
+    track, an, sc, ref, pen = track4min
+    got = an.logspec[:, :80].cpu().numpy()
+    want = ref["logspec"][:, :80]
+    u = _ulps(got, want)
+    eq = float(np.mean(u == 0))
+    print(f"\ndisplayed bins over {got.shape[0]} frames: {eq * 100:.2f} % bit-equal to the oracle, max {int(u.max())} ulp; "
+          f"all bins: max rel err {float(np.max(np.abs(an.logspec.cpu().numpy().astype(np.float64) - ref['logspec']) / np.maximum(ref['logspec'], 1e-30))):.3e}")
+    assert eq >= 0.90 and u.max() <= 2
+    # the magnitudes themselves: expm1 of the correctly rounded log1p is not the magnitude, so check them through the
+    # streaming entry point, which returns prev_mag = |X| (Analyzer.prev_mag)
+    from aurora_amd.audio.analysis import Analyzer
+    rng = np.random.default_rng(3)
+    a, r = Analyzer(48000, 2048), A.AnalyzerRef(48000, 2048)
+    for _ in range(6):
+        x = (rng.standard_normal(1024) * 0.3).astype(np.float32)
+        a.compute(x)
+        r.compute(x)
+        assert np.array_equal(a.prev_mag[:128], r.prev_mag[:128])

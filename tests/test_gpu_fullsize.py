@@ -193,3 +193,100 @@ def test_full_track_linear_waveform_shadow_properties(eng, track4min):
     line = (R.rasterize_spans(R.spans_polyline(Y, W, H), (255, 255, 255), W, H) == 255).all(axis=2)
     want[line] = _np(sc.pen_rgb)[f, :3]
     assert np.array_equal(got, want)
+
+
+# ---- configs[4] unit: one 1 h track, Spectrum - Linear 3840x2160@60, 216 000 frames, cut into 8 time shards ----------
+
+@pytest.fixture(scope="module")
+def track1h(eng):
+    from aurora_amd import synth
+    sr, fps = 48000, 60
+    audio = synth.pink_device(sr * 3600, 2, 1234, eng.device)
+    track = eng.make_track(audio, sr, fps)
+    an = eng.analyze(track)
+    sc = eng.scan(an)
+    return track, an, sc
+
+
+def _frame_digests(eng, an, sc, mode, W, H, batch=96):
+    """Wrap-around int64 checksum of every rendered frame of an analysed range (frames never leave the GPU)."""
+    import torch
+    mult = torch.arange(1, W * H * 3 // 8 + 1, dtype=torch.int64, device=eng.device)
+    per, done = [], 0
+    out = eng.empty((batch, H, W, 3), torch.uint8)
+    while done < an.n_frames:
+        n = min(batch, an.n_frames - done)
+        fr = eng.render(mode, an, sc, W, H, done, n, out=out[:n])
+        per.append((fr.view(n, -1).view(torch.int64) * mult).sum(dim=1))
+        done += n
+    return torch.cat(per)
+
+
+def test_config4_unit_properties_and_sampled_frames(eng, track1h):
+    import torch
+    track, an, sc = track1h
+    F = track.total_frames
+    assert F == 216000 and track.hop == 800
+    assert bool(an.logspec.isfinite().all()) and bool((an.logspec >= 0).all())
+    # Parseval on every frame (in chunks: the float64 temporaries of 216 000 frames do not have to coexist)
+    win = torch.from_numpy(eng.ctx.window()).to(eng.device)
+    wts = torch.full((1025,), 2.0, dtype=torch.float64, device=eng.device)
+    wts[0] = wts[1024] = 1.0
+    pos = track.pos
+    idx = torch.arange(1024, device=eng.device)
+    worst = 0.0
+    for f0 in range(0, F, 8192):
+        f1 = min(F, f0 + 8192)
+        lhs = (torch.expm1(an.logspec[f0:f1].double()) ** 2 * wts).sum(dim=1)
+        # blocks f-1 and f of every frame, gathered from the track exactly as _read_frame does (hop 800, 224 zeros)
+        fr = torch.arange(f0 - 1, f1, device=eng.device).clamp(min=0)
+        at = pos[fr][:, None] + idx[None, :]
+        ok = (idx[None, :] < track.hop) & (at < track.n_samples)
+        blk = track.audio[at.clamp(max=track.n_samples - 1)]
+        blk = ((blk[..., 0] + blk[..., 1]) * 0.5) * ok
+        if f0 == 0:
+            blk[0] = 0                                            # Analyzer.buffer starts at zero
+        buf = torch.cat([blk[:-1], blk[1:]], dim=1) * win        # float32 product, as the reference
+        rhs = 2048.0 * (buf.double() ** 2).sum(dim=1)
+        worst = max(worst, float(((lhs - rhs).abs() / rhs.clamp(min=1e-30)).max()))
+    print(f"Parseval over {F} frames: max relative deviation {worst:.3e}")
+    assert worst < 5e-6
+    # sampled frames against the oracle, re-synchronised through the 2-block halo
+    rng = np.random.default_rng(7)
+    for f in sorted(set([0, 1, F - 1] + list(rng.integers(2, F - 1, 21)))):
+        lo = max(0, f - 1)
+        a0, a1 = int(track.pos_host[lo]), min(track.n_samples, int(track.pos_host[f]) + track.hop)
+        seg = _np(track.audio[a0:a1])
+        ref = A.AnalyzerRef()
+        for g in range(lo, f + 1):
+            s = A.read_frame(seg, int(track.pos_host[g]) - a0, track.hop)
+            spec, _ = ref.compute(s)
+        assert float(sc.energy[f]) == A.frame_energy(s)
+        assert np.allclose(_np(an.logspec[f]), spec, rtol=1e-4, atol=1e-9), f
+        ulp = np.abs(_np(an.logspec[f, :80]).view(np.int32).astype(np.int64) - spec[:80].view(np.int32).astype(np.int64))
+        assert ulp.max() <= 2, f
+
+
+def test_config4_unit_eight_time_shards_byte_identical(eng, track1h):
+    """The eight `sharding.frame_range(216000, 8, r)` cuts of BASELINE.json configs[4]: every shard's analysis values,
+    carried smoothing state and RENDERED 4K FRAMES (per-frame checksums of all 216 000 frames) equal the unsharded run."""
+    import torch
+    from aurora_amd import sharding
+    track, an, sc = track1h
+    F = track.total_frames
+    W, H = 3840, 2160
+    whole = _frame_digests(eng, an, sc, "Spectrum - Linear", W, H)
+    assert whole.numel() == F
+    for r in range(8):
+        a, b = sharding.frame_range(F, 8, r)
+        assert (a, b) == (27000 * r, 27000 * (r + 1))
+        part = eng.analyze(track, a, b - a)
+        state = eng.carried_state(track, a)
+        psc = eng.scan(part, state=state)
+        assert torch.equal(part.logspec, an.logspec[a:b]) and torch.equal(part.flux_sum, an.flux_sum[a:b])
+        assert torch.equal(part.meanabs, an.meanabs[a:b])
+        assert torch.equal(psc.energy, sc.energy[a:b]) and torch.equal(psc.pen_rgb, sc.pen_rgb[a:b])
+        assert torch.equal(psc.flux_smooth, sc.flux_smooth[a:b]) and torch.equal(psc.phase, sc.phase[a:b])
+        if b == F:
+            assert torch.equal(psc.state, sc.state)
+        assert torch.equal(_frame_digests(eng, part, psc, "Spectrum - Linear", W, H), whole[a:b]), r

@@ -72,7 +72,11 @@ def test_analysis_vs_reference_fixtures(eng, name):
     assert np.array_equal(_np(sc.phase), g["phase"])
     ls = _np(an.logspec)
     assert np.allclose(ls, g["logspec"], rtol=RTOL, atol=ATOL), float(np.max(np.abs(ls - g["logspec"])))
-    assert np.allclose(ls[:, :80], g["logspec"][:, :80], rtol=RTOL, atol=ATOL)
+    # displayed bins: the reference's own magnitude chain + a correctly rounded log1p: within 2 ulp of the fixture
+    ulp = np.abs(ls[:, :80].view(np.int32).astype(np.int64) - g["logspec"][:, :80].view(np.int32).astype(np.int64))
+    # (>= 91 % bit-equal on pink noise; 76 % on the sweep, whose displayed bins are leakage 9 decades under the frame's
+    # peak: there the two float64 FFTs -- pocketfft and this kernel -- differ by 1e-16 of the peak = a float32 ulp of the bin)
+    assert ulp.max() <= 2 and np.mean(ulp == 0) >= 0.70, (int(ulp.max()), float(np.mean(ulp == 0)))
     assert np.allclose(_np(sc.flux_smooth), g["flux_smooth"], rtol=1e-5, atol=1e-7)
     bm = _np(an.bandmax)
     assert np.array_equal(bm[:, 0], ls[:, :80].max(axis=1)) and np.array_equal(bm[:, 1], ls[:, :50].max(axis=1))
@@ -232,6 +236,7 @@ def test_spans_vs_reference_drawlists(eng, fixture):
     ls = _np(an.logspec)
     keys = sorted(k[:-4] for k in g.files if k.endswith("_pen") and not k.startswith("radial"))
     assert keys
+    checked = moved = 0                      # bar tops / particle rows compared, and how many sit one row off
     for k in keys:
         tag, wh, fs = k.split("_")
         W, H = (int(v) for v in wh.split("x"))
@@ -253,11 +258,20 @@ def test_spans_vs_reference_drawlists(eng, fixture):
                 x, y = int(pts[i, 0]), int(pts[i, 1])
                 r0 = int(got[x, 0, 0])
                 assert abs((r0 + 1) - y) <= 1, (k, i)
+                checked += 1
+                moved += (r0 + 1) != y
         else:
             lines = g[k + "_lines"]
             for i in range(80):
                 x0, top = int(lines[i, 0]), int(lines[i, 3])
                 assert got[x0, 0, 1] == H - 4 and abs((int(got[x0, 0, 0]) + 1) - top) <= 1, (k, i)
+                checked += 1
+                moved += (int(got[x0, 0, 0]) + 1) != top
+    # the displayed bins follow the reference's magnitude / log1p chain (csrc/stft.hip: cabs_c64, log1p_cr): what is left is
+    # numpy's SVML log1p being 1-2 ulp off the correctly rounded value in 8 % of the bins; a one-row move needs that AND
+    # int() sitting on the edge.  Measured on MI355X: 0 of the bar tops / particle rows of both fixtures move.
+    print(f"{fixture}: {moved} of {checked} bar tops / particle rows one row off the reference's draw calls")
+    assert moved <= max(1, checked // 2000)
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -277,7 +291,9 @@ def test_end_to_end_vs_oracle_psnr(eng, mode):
         bad_px = max(bad_px, int(np.sum(np.abs(frames[f].astype(int) - want.astype(int)).max(axis=2) > 1)))
     print(f"{mode}: min PSNR {worst:.1f} dB, max pixels off by >1 LSB in a frame: {bad_px}")
     assert worst >= 50.0
-    assert bad_px <= 8        # at most a few one-row bar-height flips (2 px each) from fp32-FFT rounding
+    # one bar top or one particle a row off = 2 pixels (tests/test_gpu_e2e_parity.py measures the rate of such frames at
+    # full size: 0 of 2000 at 1080p, 2 of 2000 at 4K, never more than 2 pixels)
+    assert bad_px <= 2
 
 
 def test_pipeline_readback_and_shards_byte_identical(eng):
@@ -958,3 +974,36 @@ def test_wave_linear_vertices_match_drawlist(eng):
         Y = R.drawlist_waveform_linear(samples[f], float(energy[f]), W, H)
         assert np.array_equal(got[f, :, 0], np.arange(W, dtype=np.float64))
         assert np.array_equal(got[f, :, 1], Y)
+
+
+@pytest.mark.parametrize("mode", ["Spectrum - Linear", "Spectrum - Radial", "Waveform - Linear"])
+def test_render_time_duck_type_equals_stream(eng, mode):
+    """The reference's renderer duck type, `.duration` + `.render_time(t)` driven frame by frame with t = i / fps exactly as
+    `Exporter._run_pipe` does (export/exporter.py:536-542, :246-252), against the batched `stream_to` path."""
+    import io
+    from aurora_amd import synth
+    from aurora_amd.export.exporter import Exporter, HipOffscreenRenderer
+    W, H, sr, fps = 640, 360, 44100, 30            # hop 1470 > 1024 and t * fps not always an integer in float
+    audio = synth.pink(sr * 3 + 311, 2, seed=21)
+    vs = {"hip_batch_frames": 16}
+    fast = HipOffscreenRenderer(W, H, mode, (0.2, 0.8, 1.0), 1.3, fps, (audio, sr), **vs)
+    buf = io.BytesIO()
+    n = fast.stream_to(buf)
+    assert n == fast.total_frames == int(np.ceil(fast.duration * fps))
+
+    class OnlyDuck:                                   # hides stream_to: Exporter._pump takes the reference's loop
+        def __init__(self, r):
+            self.duration = r.duration
+            self.render_time = r.render_time
+
+    slow = HipOffscreenRenderer(W, H, mode, (0.2, 0.8, 1.0), 1.3, fps, (audio, sr), **vs)
+    ex = Exporter((audio, sr), W, H, fps, mode, sensitivity=1.3, view_state=vs)
+    buf2 = io.BytesIO()
+    pct = []
+    written = ex._pump(OnlyDuck(slow), buf2, pct.append)
+    assert written == n and buf2.getvalue() == buf.getvalue()
+    assert pct and pct[0] == 0 and all(b >= a for a, b in zip(pct[:-1], pct[1:]))
+    # random access (the duck type allows any t): a frame far from the cached batch, then one before it
+    fr = slow.render_time(70 / fps)
+    assert fr.shape == (H, W, 3) and fr.tobytes() == buf.getvalue()[70 * W * H * 3:71 * W * H * 3]
+    assert slow.render_time(3 / fps).tobytes() == buf.getvalue()[3 * W * H * 3:4 * W * H * 3]

@@ -465,3 +465,54 @@ def test_load_audio_wav_variants_and_ffmpeg_fallback(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError) as ei:
         E.load_audio(str(mp3))
     assert str(ei.value) == "ffmpeg not found for decoding non-WAV formats."
+
+
+def test_frame_compare_worker_in_spawned_pool():
+    """The worker of tests/test_gpu_e2e_parity.py (oracle render + compare through shared memory, spawned processes)."""
+    import multiprocessing as mp
+    from multiprocessing import shared_memory
+    from _frame_compare_worker import compare_frame
+    from oracle import raster_ref as R
+    W, H = 320, 180
+    rng = np.random.default_rng(0)
+    spec = rng.random(1025).astype(np.float32)
+    smp = rng.random(1024).astype(np.float32) - 0.5
+    fr = R.render_frame("Spectrum - Linear", smp, spec, 0.3, (1, 2, 3), W, H)
+    fb = W * H * 3
+    shm = shared_memory.SharedMemory(create=True, size=2 * fb)
+    try:
+        v = np.ndarray((2, H, W, 3), np.uint8, buffer=shm.buf)
+        v[0] = fr
+        v[1] = fr
+        v[1, 100, 100] = (9, 9, 9)
+        del v
+        with mp.get_context("spawn").Pool(2) as p:
+            res = p.map_async(compare_frame, [(shm.name, j * fb, "Spectrum - Linear", smp, spec, 0.3, (1, 2, 3), W, H)
+                                              for j in range(2)]).get(timeout=60)
+    finally:
+        shm.close()
+        shm.unlink()
+    assert res[0] == (0, 0, float("inf"))
+    assert res[1][0] == 1 and res[1][1] == 1 and res[1][2] > 40
+
+
+def test_numpy_cabs_formula():
+    """np.abs(complex64) on this host == max * sqrt(fma(d, d, 1)), d = min / max in float32 -- the formula
+    csrc/stft.hip:cabs_c64 evaluates for the displayed bins.  numpy's AVX2 / AVX-512 loops use it when FMA3 is there;
+    a host without FMA3 takes another path, and then the fixtures (generated on an FMA3 host) are the pin, not this test."""
+    from numpy._core._multiarray_umath import __cpu_features__ as feat
+    if not (feat.get("FMA3") and feat.get("AVX2")):
+        pytest.skip("host numpy has no AVX2 + FMA3 dispatch")
+    rng = np.random.default_rng(0)
+    n = 2_000_000
+    z = (rng.standard_normal(n) * 10 ** rng.uniform(-6, 3, n)
+         + 1j * rng.standard_normal(n) * 10 ** rng.uniform(-6, 3, n)).astype(np.complex64)
+    z[:4] = [0, 1, 1j, 3 + 4j]
+    f32 = np.float32
+    a, b = np.abs(z.real), np.abs(z.imag)
+    mx, mn = np.maximum(a, b), np.minimum(a, b)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        d = np.where(mx > 0, mn / mx, 0).astype(f32)
+    fma = (d.astype(np.float64) * d.astype(np.float64) + 1.0).astype(f32)     # exact product, one rounding
+    want = (mx * np.sqrt(fma)).astype(f32)
+    assert np.array_equal(np.abs(z), want)

@@ -418,9 +418,9 @@ class HipExportEngine:
     def scan(self, an: Analysis, params: _lib.ScanParams | None = None, state=None) -> Scan:
         """state: None (track start) or (amp_ema, flux_smooth, phase) carried from the previous shard."""
         torch = self.torch
-        p = _lib.ScanParams.defaults() if params is None else params
-        if state is not None:
-            p.amp_ema0, p.flux_smooth0, p.phase0 = (float(v) for v in state)
+        # a private copy: the carried state of THIS call never leaks into the caller's (reusable) parameter object
+        p = _lib.ScanParams.defaults() if params is None else _lib.ScanParams.from_buffer_copy(params)
+        p.amp_ema0, p.flux_smooth0, p.phase0 = (float(v) for v in state) if state is not None else (0.0, 0.0, 0.0)
         F = an.n_frames
         energy = self.empty((F,), torch.float64)
         pen = self.empty((F, 4), torch.uint8)

@@ -22,6 +22,7 @@ import os
 import platform
 import shutil
 import subprocess
+import threading
 import wave
 from pathlib import Path
 from typing import Dict, List, Optional, Tuple
@@ -325,6 +326,39 @@ class _PipeSink:
         self._stdin.write(buf)
 
 
+class _TailReader:
+    """Reads a child's pipe to its end on a daemon thread, keeping the last ``keep`` bytes."""
+
+    def __init__(self, stream, keep):
+        self._stream, self._keep, self._chunks, self._size = stream, int(keep), [], 0
+        self._thread = None
+        if stream is not None:
+            self._thread = threading.Thread(target=self._drain, name="aurora-ffmpeg-drain", daemon=True)
+            self._thread.start()
+
+    def _drain(self):
+        try:
+            while True:
+                chunk = self._stream.read1(1 << 16) if hasattr(self._stream, "read1") else self._stream.read(1 << 16)
+                if not chunk:
+                    return
+                if self._keep:
+                    self._chunks.append(chunk)
+                    self._size += len(chunk)
+                    while self._size - len(self._chunks[0]) >= self._keep:
+                        self._size -= len(self._chunks.pop(0))
+        except Exception:
+            pass
+
+    def join(self):
+        if self._thread is not None:
+            self._thread.join()
+
+    def text(self):
+        self.join()
+        return b"".join(self._chunks)[-self._keep:].decode("utf-8", errors="ignore") if self._keep else ""
+
+
 class Exporter:
     def __init__(self, audio_path, width=1920, height=1080, fps=60, mode="Waveform - Linear",
                  color=(0.2, 0.8, 1.0), sensitivity=1.0, prefer_hevc=False, view_state=None,
@@ -393,6 +427,11 @@ class Exporter:
     def _run_pipe(self, renderer, cmd, progress_cb=None):
         proc = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                 bufsize=10 ** 7)
+        # FFmpeg prints statistics while it encodes: both pipes are drained while the frames are written, or the child
+        # blocks on a full pipe a few minutes in and the writer behind it for good.  The tail of stderr is kept for the
+        # error message.
+        tail = _TailReader(proc.stderr, keep=1 << 16)
+        sinkhole = _TailReader(proc.stdout, keep=0)
         try:
             self._pump(renderer, _PipeSink(proc.stdin), progress_cb)
         finally:
@@ -401,11 +440,9 @@ class Exporter:
                     proc.stdin.close()
             except Exception:
                 pass
-        try:
-            stderr = proc.stderr.read().decode("utf-8", errors="ignore") if proc.stderr else ""
-        except Exception:
-            stderr = ""
         code = proc.wait()
+        stderr = tail.text()
+        sinkhole.join()
         if progress_cb:
             try:
                 progress_cb(100)

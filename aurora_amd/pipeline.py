@@ -107,6 +107,9 @@ class FramePipeline:
         self.glow = glow if (glow is not None and glow.active and self.planes) else None
         self._analysed = None
         self._radial_prep = None
+        self._ring = None
+        self.fill_events = None      # benchmarks set a list: (start, end, n_frames) HIP events around every fill launch
+        self.stft_events = None      # the same around the fused STFT launch of analyse()
 
     # ---- phase 1: analysis + scan of the whole shard (about 10 KB per frame) -------------------------
     def analyse(self):
@@ -114,7 +117,13 @@ class FramePipeline:
             eng = self.eng
             state = eng.carried_state(self.track, self.frame_begin, self.params) if self.frame_begin > 0 else None
             n = self.frame_end - self.frame_begin
+            if self.stft_events is not None:
+                e0, e1 = eng.torch.cuda.Event(enable_timing=True), eng.torch.cuda.Event(enable_timing=True)
+                e0.record()
             an = eng.analyze(self.track, self.frame_begin, n, want_samples=self.kind.startswith("waveform"))
+            if self.stft_events is not None:
+                e1.record()
+                self.stft_events.append((e0, e1, n))
             sc = eng.scan(an, self.params, state)
             if self.radial is not None:
                 rstate = eng.carried_radial_state(self.track, self.frame_begin, self.radial)
@@ -137,16 +146,31 @@ class FramePipeline:
         if self.kind == "waveform_circular":
             return self.eng.render_wave_circular(an, sc, self.W, self.H, first, count, self.rotation_deg, out=out,
                                                  planes_out=scratch, fill=self.fill, shadow=self.shadow, glow=self.glow)
-        return self.eng.render(self.mode, an, sc, self.W, self.H, first, count, out=out, spans_out=scratch)
+        ev = self.fill_events
+        if ev is None:
+            return self.eng.render(self.mode, an, sc, self.W, self.H, first, count, out=out, spans_out=scratch)
+        # benchmark instrumentation: the same three launches as eng.render, with HIP events around the fill kernel alone
+        # (recorded on the stream the kernels are launched on)
+        torch = self.eng.torch
+        n = an.n_frames - first if count is None else count
+        spans, K = self.eng.spans(self.kind, an, sc, self.W, self.H, first, n, out=scratch)
+        work = self.eng.summarize(spans, K, self.W, self.H)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = self.eng.fill(spans, K, sc.pen_rgb[first:first + n], self.W, self.H, out=out, work=work, work_ready=True)
+        e1.record()
+        ev.append((e0, e1, n))
+        return out
 
     # ---- full pipeline: GPU -> pinned host ring -> sink --------------------------------------------------
-    def run(self, sink, progress=None):
-        """Renders every frame of the shard in order into ``sink.write``.  Returns the number of frames."""
+    def prepare(self):
+        """Allocates the device slots, the pinned host ring and the copy stream once (idempotent).  `run` does it on its
+        own when nobody did; a caller that exports repeatedly (benchmarks, many tracks of one size) calls it once and
+        `close()` at the end, so that no allocation sits inside a run."""
+        if self._ring is not None:
+            return self
         eng, torch = self.eng, self.eng.torch
-        an, sc = self.analyse()
-        n_total = self.frame_end - self.frame_begin
-        if n_total == 0:
-            return 0
+        n_total = max(1, self.frame_end - self.frame_begin)
         B, S = min(self.batch, n_total), self.slots
         dev_frames = [eng.empty((B, self.H, self.W, 3), torch.uint8) for _ in range(S)]
         yuv = self.wire_format == "yuv420p"
@@ -158,7 +182,37 @@ class FramePipeline:
                  "waveform_linear": _lib.K_WAVEFORM}[self.kind]
             dev_spans = [eng.empty((B, K, self.W), torch.int32) for _ in range(S)]
         host = [_PinnedSlot(eng.lib, B * self.frame_bytes) for _ in range(S)]
-        copy_stream = torch.cuda.Stream(device=eng.device)
+        self._ring = dict(B=B, S=S, dev_frames=dev_frames, dev_wire=dev_wire, dev_spans=dev_spans, host=host,
+                          copy_stream=torch.cuda.Stream(device=eng.device))
+        return self
+
+    def close(self):
+        """Frees the pinned ring (device tensors go back to torch's allocator with the object)."""
+        if self._ring is not None:
+            self.eng.torch.cuda.synchronize(self.eng.device)
+            for h in self._ring["host"]:
+                h.free()
+            self._ring = None
+
+    def reset_analysis(self):
+        """Forget the analysed shard: the next run / render analyses again (benchmark steps time the whole job)."""
+        self._analysed = None
+        self._radial_prep = None
+
+    def run(self, sink, progress=None):
+        """Renders every frame of the shard in order into ``sink.write``.  Returns the number of frames."""
+        eng, torch = self.eng, self.eng.torch
+        an, sc = self.analyse()
+        n_total = self.frame_end - self.frame_begin
+        if n_total == 0:
+            return 0
+        own_ring = self._ring is None
+        self.prepare()
+        ring = self._ring
+        B, S = ring["B"], ring["S"]
+        dev_frames, dev_wire, dev_spans, host = ring["dev_frames"], ring["dev_wire"], ring["dev_spans"], ring["host"]
+        copy_stream = ring["copy_stream"]
+        yuv = self.wire_format == "yuv420p"
         copied = [None] * S                    # event: slot's D2H copy finished
         free_slots = threading.Semaphore(S)    # host slot consumed by the writer
         q: "queue.Queue" = queue.Queue()
@@ -221,8 +275,8 @@ class FramePipeline:
             q.put(None)
             th.join()
             torch.cuda.synchronize(eng.device)
-            for h in host:
-                h.free()
+            if own_ring:
+                self.close()
         if err and not isinstance(err[0], BrokenPipeError):
             raise err[0]
         return done

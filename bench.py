@@ -4,18 +4,25 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (per GPU, per step): one unit of BASELINE.json configs[4] -- a 1 h, 48 kHz, stereo synthetic pink-noise
-track exported in "Spectrum - Linear" mode at 3840x2160@60 = 216 000 frames.  A step runs the whole device path
-over that track: fused STFT analysis (1 launch) -> smoothing scan -> column spans -> RGB24 fill of every frame
-into a ring of device slots (frames stay in HBM; the PCIe-inclusive rate is measured separately and reported as
-`pcie_inclusive_fps`, never as `value`).  Ranks take different tracks (time/track sharding, no collective): weak
-scaling, value = N * frames / max-over-ranks step time.
+`value` is what BASELINE.json names: frames per second that REACH THE HOST SINK.  A step is one whole export of a
+synthetic track that is already resident in HBM (default: 240 s of 48 kHz stereo pink noise, "Spectrum - Linear"
+3840x2160@60 = 14 400 frames, the track length of configs[1..3] at the headline mode of configs[4]): fused STFT
+analysis -> smoothing scan -> column spans -> RGB24 fill in batches -> hipMemcpyAsync into a pinned host ring on a
+side stream -> a writer thread hands every slot to the sink (a null sink: FFmpeg is excluded on the GPU and the CPU
+side alike).  The ring is allocated before the clock starts.  Ranks export different tracks (time/track sharding, no
+collective): weak scaling, value = N * frames / max-over-ranks time.  That rate is bound by the PCIe link of each GPU
+(`roofline_pcie`), not by HBM.
 
-The JSON line also carries
-  roofline      : the dominant kernel (raster fill), algorithmic bytes W*H*3 per frame / HIP-event time
-  roofline_stft : the fused STFT kernel, algorithmic bytes 4*C*min(hop,1024) + 4*1025 + 8 per frame
-  cpu_baseline  : the numpy oracle (a port of the reference's CPU path) timed on one host core over a bounded
-                  sample of the same workload (rank 0, N=1 only).
+Next to it the JSON line carries
+  roofline      : the dominant kernel of the step (raster fill), algorithmic bytes W*H*3 per frame / HIP-event time
+                  around every fill launch of the timed region
+  roofline_pcie : bytes per frame over the link vs its 63 GB/s
+  device_leg    : the same path with the frames left in HBM (a 2-slot ring that is overwritten), over the configs[4]
+                  unit (1 h track, 216 000 frames per step): `device_fps`, and `roofline_stft` -- the fused STFT kernel
+                  over 216 000 frames per launch, algorithmic bytes 4*C*min(hop,1024) + 4*1025 + 8 per frame, against
+                  HBM and against the vector-ALU issue roof that actually bounds it
+  cpu_baseline  : the numpy oracle (a port of the reference's CPU path) timed on one host core -- how the reference
+                  runs -- and on all cores of the box's share, over a bounded sample of the same workload (rank 0, N=1)
 """
 from __future__ import annotations
 
@@ -30,6 +37,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PCIE_PEAK_GBS = 63.0           # same guide: host link PCIe Gen5 x16, 63 GB/s
+F64_ISSUE_NS = 2.18            # profiles/r01_f64_issue_probe.txt: ns per VALU wave-instruction per SIMD under this load
 
 
 def parse_args():
@@ -37,45 +46,87 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--seconds", type=float, default=3600.0, help="track length per GPU per step")
+    ap.add_argument("--seconds", type=float, default=240.0, help="track length per GPU per step (the exported track)")
     ap.add_argument("--sample-rate", type=int, default=48000)
     ap.add_argument("--fps", type=int, default=60)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--mode", default="Spectrum - Linear")
     ap.add_argument("--glow", action="store_true", help="closed-path modes: add the glow decoration (7 additive strokes)")
-    ap.add_argument("--batch", type=int, default=128, help="frames per raster launch (device slot size)")
+    ap.add_argument("--batch", type=int, default=64, help="frames per raster launch / ring slot")
+    ap.add_argument("--slots", type=int, default=3, help="ring slots in flight")
+    ap.add_argument("--wire", default="rgb24", choices=("rgb24", "yuv420p"), help="wire format of the headline leg")
+    ap.add_argument("--device-seconds", type=float, default=3600.0, help="track of the device-side leg (configs[4] unit)")
+    ap.add_argument("--device-steps", type=int, default=2, help="timed steps of the device-side leg (0 = skip)")
     ap.add_argument("--cpu-frames", type=int, default=240, help="frames of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--pcie-frames", type=int, default=1024, help="frames of the PCIe-inclusive leg (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-cores CPU figure (0 = box share)")
+    ap.add_argument("--yuv-leg", type=int, default=1, help="also time one export step in the opt-in yuv420p wire format")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-launch HBM bytes from separate rocprofv3 --pmc passes (see profiles/README.md)")
+    ap.add_argument("--isa-json", default=os.path.join(ROOT, "profiles", "stft_isa.json"),
+                    help="VALU instructions per frame of the STFT loop (tools/stft_isa.py)")
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """The oracle (port of export/exporter.py:538-544 + rt_widget.py paint_frame) on one host core."""
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+
+def _cpu_export(job):
+    """The oracle (port of export/exporter.py:538-544 + rt_widget.py paint_frame) over `frames` frames -> seconds."""
     import numpy as np
     from aurora_amd import synth
     from oracle import analysis_ref as A      # checker / baseline only
     from oracle import raster_ref as R
-
-    sr, fps, W, H = args.sample_rate, args.fps, args.width, args.height
-    n = int(args.cpu_frames * sr / fps)
-    audio = synth.pink(n, 2, seed=1234)
+    mode, sr, fps, W, H, frames, seed = job
+    audio = synth.pink(int(frames * sr / fps), 2, seed=seed)
     sunk = 0
     t0 = time.perf_counter()
     ref = A.analyze_track(audio, sr, fps)
     pen, _ = A.amp_to_color_track(ref["energy"])
     F = ref["samples"].shape[0]
     for f in range(F):
-        frame = R.render_frame(args.mode, ref["samples"][f], ref["logspec"][f], float(ref["energy"][f]), pen[f], W, H)
+        frame = R.render_frame(mode, ref["samples"][f], ref["logspec"][f], float(ref["energy"][f]), pen[f], W, H)
         frame = np.ascontiguousarray(frame)            # exporter.py:540
         sunk += len(frame.tobytes())                   # exporter.py:542 -> null sink
-    dt = time.perf_counter() - t0
-    return {"value": F / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"first {F} frames ({F / fps:.1f} s of audio) of the same workload: numpy oracle analysis + "
-                      f"software rasteriser + ascontiguousarray/tobytes into a null sink, {dt:.1f} s on 1 core "
-                      f"of {os.cpu_count()} visible"}
+    return F, time.perf_counter() - t0
+
+
+def cpu_baseline(args):
+    import multiprocessing as mp
+    sr, fps, W, H = args.sample_rate, args.fps, args.width, args.height
+    F, dt = _cpu_export((args.mode, sr, fps, W, H, args.cpu_frames, 1234))
+    out = {"value": round(F / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"first {F} frames ({F / fps:.1f} s of audio) of the same workload: numpy oracle analysis + software "
+                     f"rasteriser + ascontiguousarray/tobytes into a null sink, {dt:.1f} s on 1 core (the reference "
+                     f"exports in one process, export/worker.py)"}
+    # courtesy whole-host figure (BASELINE.md 4(b)): independent processes over disjoint time ranges of the track
+    procs = args.cpu_procs or min(16, os.cpu_count() or 1)      # a 1-GPU box's CPU share is 16 (nproc shows the machine)
+    if procs > 1:
+        per = max(30, args.cpu_frames // 2)
+        ctx = mp.get_context("spawn")                            # this process has initialised the GPU: never fork it
+        t0 = time.perf_counter()
+        with ctx.Pool(procs) as pool:
+            res = pool.map(_cpu_export, [(args.mode, sr, fps, W, H, per, 1234 + 7 * k) for k in range(procs)])
+        wall = time.perf_counter() - t0
+        busy = max(r[1] for r in res)
+        out["all_cores"] = {"value": round(sum(r[0] for r in res) / busy, 2), "unit": "frames/s", "cores": procs,
+                            "sample": f"{procs} processes x {per} frames of disjoint ranges, slowest process {busy:.1f} s "
+                                      f"({wall:.1f} s with interpreter start-up)"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- helpers
+
+def kernel_stats(events, bytes_per_frame):
+    ms = sum(a.elapsed_time(b) for a, b, _ in events)
+    frames = sum(n for _, _, n in events)
+    launches = len(events)
+    if launches == 0 or ms <= 0:
+        return None
+    gbs = frames * bytes_per_frame / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "avg_launch_ms": round(ms / launches, 4), "frames_per_launch": round(frames / launches, 1),
+            "algorithmic_bytes_per_frame": bytes_per_frame}
 
 
 def main():
@@ -108,158 +159,224 @@ def main():
 
     eng = get_engine(dev_index)
     sr, fps, W, H = args.sample_rate, args.fps, args.width, args.height
-    n_samples = int(round(args.seconds * sr))
-    audio = synth.pink_device(n_samples, 2, 1234 + rank, device)      # input resident in HBM before timing
-    track = eng.make_track(audio, sr, fps)
-    F = track.total_frames
-    # BASELINE.json configs[3]: "particle mode + audio-reactive image feather".  The reference draws the centre disc and
-    # its feather only in "Spectrum - Radial" (rt_widget.py:841-849), so this is the union of the work (SURVEY.md 0):
-    # particle frames with the audio-reactive disc envelope and the six feather rings composited on top.
-    union = args.mode == "Particles + Feather"
-    kind = mode_kind("Particles" if union else args.mode)
-    radial = RadialConfig() if kind == "spectrum_radial" else None
-    feather = RadialConfig(feather_enabled=True, feather_audio_enabled=True, feather_audio_amount=60,
-                           edge_waviness=40) if union else None
-    circular = kind == "waveform_circular"
-    planes_mode = radial is not None or circular
-    K = {"spectrum_linear": _lib.K_SPECTRUM, "particles": _lib.K_PARTICLES, "waveform_linear": _lib.K_WAVEFORM,
-         "spectrum_radial": 0, "waveform_circular": 0}[kind]
-    B = max(1, min(args.batch, F))
-    slots = 2
-    dev_frames = [eng.empty((B, H, W, 3), torch.uint8) for _ in range(slots)]
-    if planes_mode:
-        dev_spans = [eng.empty((2, B, H, (W + 31) // 32), torch.int32) for _ in range(slots)]
-    else:
-        dev_spans = [eng.empty((B, K, W), torch.int32) for _ in range(slots)]
     frame_bytes = W * H * 3
-    stft_bytes = 4 * track.channels * min(track.hop, 1024) + 4 * 1025 + 8
-
-    def step(ev_fill=None, ev_stft=None):
-        if ev_stft is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        an = eng.analyze(track, want_samples=kind.startswith("waveform"))
-        if ev_stft is not None:
-            e1.record()
-            ev_stft.append((e0, e1, F))
-        sc = eng.scan(an)
-        prep = eng.radial_prepare(an, radial or feather) if (radial or feather) is not None else None
-        done, i = 0, 0
-        while done < F:
-            n = min(B, F - done)
-            s = i % slots
-            if radial is not None:
-                planes = eng.radial_planes(prep, an, sc, W, H, done, n, planes_out=dev_spans[s][:, :n])
-            elif circular:
-                planes = eng.wave_circular_planes(an, sc, W, H, done, n, planes_out=dev_spans[s][:, :n])
-            else:
-                spans, _ = eng.spans(kind, an, sc, W, H, done, n, out=dev_spans[s][:n])
-                work = eng.summarize(spans, K, W, H)           # column summaries: their own small kernel
-            if ev_fill is not None:                            # the events bracket the fill kernel alone
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            if planes_mode:
-                eng.fill_planes(planes, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n])
-            else:
-                eng.fill(spans, K, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n], work=work, work_ready=True)
-            if ev_fill is not None:
-                e1.record()
-                ev_fill.append((e0, e1, n))
-            if args.glow and planes_mode:
-                verts = (eng.radial_path_vertices(prep, sc, W, H, done, n) if radial is not None
-                         else eng.wave_circular_vertices(an, sc, W, H, done, n))
-                eng.apply_glow(GlowConfig(enabled=True), verts, sc, done, n, planes[0], planes[1], planes[2],
-                               dev_frames[s][:n])
-            if feather is not None:
-                eng.feather_blend(prep, an, sc, W, H, done, n, dev_frames[s][:n], with_disc=True)
-            done += n
-            i += 1
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # BASELINE.json configs[3]: "particle mode + audio-reactive image feather".  The reference draws the centre disc and
+    # its feather only in "Spectrum - Radial" (rt_widget.py:841-849), so this is the union of the work (SURVEY.md 0):
+    # particle frames with the audio-reactive disc envelope and the six feather rings composited on top (device leg only).
+    union = args.mode == "Particles + Feather"
+    kind = mode_kind("Particles" if union else args.mode)
+    planes_mode = kind in ("spectrum_radial", "waveform_circular")
+    K = {"spectrum_linear": _lib.K_SPECTRUM, "particles": _lib.K_PARTICLES, "waveform_linear": _lib.K_WAVEFORM,
+         "spectrum_radial": 0, "waveform_circular": 0}[kind]
+
+    # ------------------------------------------------------------------ headline: export into the host sink
+    n_samples = int(round(args.seconds * sr))
+    audio = synth.pink_device(n_samples, 2, 1234 + rank, device)      # input resident in HBM before timing
+    track = eng.make_track(audio, sr, fps)
+    F = track.total_frames
+    stft_bytes = 4 * track.channels * min(track.hop, 1024) + 4 * 1025 + 8
+    export_mode = "Particles" if union else args.mode
+    B = max(1, min(args.batch, F))
+
+    def make_pipe(wire):
+        return FramePipeline(eng, track, export_mode, W, H, batch_frames=B, slots=args.slots, wire_format=wire,
+                             glow=GlowConfig(enabled=True) if args.glow else None).prepare()
+
+    def export_step(pipe):
+        pipe.reset_analysis()                      # a step is the whole job: analysis + scan + raster + readback
+        sink = NullSink()
+        n = pipe.run(sink)
+        assert n == F and sink.bytes == F * pipe.frame_bytes
+        return n
+
+    pipe = make_pipe(args.wire)                    # device slots + pinned ring allocated here, before the clock
     for _ in range(args.warmup):
-        step()
-    ev_fill, ev_stft = [], []
+        export_step(pipe)
+    ev_fill, ev_stft_small = [], []
+    if not planes_mode:
+        pipe.fill_events = ev_fill
+    pipe.stft_events = ev_stft_small
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(ev_fill, ev_stft)
+        export_step(pipe)
     barrier()
     dt = time.perf_counter() - t0
     dt = sharding.max_over_ranks(dt, device if backend == "nccl" else None)
-
-    def kernel_stats(events, bytes_per_frame):
-        ms = sum(a.elapsed_time(b) for a, b, _ in events)
-        frames = sum(n for _, _, n in events)
-        launches = len(events)
-        if launches == 0 or ms <= 0:
-            return None
-        gbs = frames * bytes_per_frame / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_launch_ms": round(ms / launches, 4), "frames_per_launch": round(frames / launches, 1),
-                "algorithmic_bytes_per_frame": bytes_per_frame}
-
     roof = kernel_stats(ev_fill, frame_bytes)
-    roof_stft = kernel_stats(ev_stft, stft_bytes)
+    wire_bytes = pipe.frame_bytes
+    pipe.fill_events = pipe.stft_events = None
+    pipe.close()
+    del pipe
+    value = world * F * args.steps / dt
+    link_gbs = F * args.steps / dt * wire_bytes / 1e9                 # per GPU (the slowest rank's)
+
+    yuv_fps = None
+    if args.yuv_leg and rank == 0 and args.wire == "rgb24" and W % 4 == 0 and H % 2 == 0:
+        p2 = make_pipe("yuv420p")
+        export_step(p2)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        export_step(p2)
+        yuv_fps = F / (time.perf_counter() - t1)
+        yuv_bytes = p2.frame_bytes
+        p2.close()
+        del p2
+    del track, audio
+    torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ device-side leg (frames stay in HBM)
+    device_leg = None
+    roof_stft = None
+    if args.device_steps > 0:
+        dn = int(round(args.device_seconds * sr))
+        daudio = synth.pink_device(dn, 2, 1234 + rank, device)
+        dtrack = eng.make_track(daudio, sr, fps)
+        DF = dtrack.total_frames
+        radial = RadialConfig() if kind == "spectrum_radial" else None
+        feather = RadialConfig(feather_enabled=True, feather_audio_enabled=True, feather_audio_amount=60,
+                               edge_waviness=40) if union else None
+        circular = kind == "waveform_circular"
+        DB = max(1, min(args.batch, DF))
+        slots = 2
+        dev_frames = [eng.empty((DB, H, W, 3), torch.uint8) for _ in range(slots)]
+        if planes_mode:
+            dev_spans = [eng.empty((2, DB, H, (W + 31) // 32), torch.int32) for _ in range(slots)]
+        else:
+            dev_spans = [eng.empty((DB, K, W), torch.int32) for _ in range(slots)]
+
+        def step(ev_f=None, ev_s=None):
+            if ev_s is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            an = eng.analyze(dtrack, want_samples=kind.startswith("waveform"))
+            if ev_s is not None:
+                e1.record()
+                ev_s.append((e0, e1, DF))
+            sc = eng.scan(an)
+            prep = eng.radial_prepare(an, radial or feather) if (radial or feather) is not None else None
+            done, i = 0, 0
+            while done < DF:
+                n = min(DB, DF - done)
+                s = i % slots
+                if radial is not None:
+                    planes = eng.radial_planes(prep, an, sc, W, H, done, n, planes_out=dev_spans[s][:, :n])
+                elif circular:
+                    planes = eng.wave_circular_planes(an, sc, W, H, done, n, planes_out=dev_spans[s][:, :n])
+                else:
+                    spans, _ = eng.spans(kind, an, sc, W, H, done, n, out=dev_spans[s][:n])
+                    work = eng.summarize(spans, K, W, H)           # column summaries: their own small kernel
+                if ev_f is not None:                               # the events bracket the fill kernel alone
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                if planes_mode:
+                    eng.fill_planes(planes, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n])
+                else:
+                    eng.fill(spans, K, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n], work=work, work_ready=True)
+                if ev_f is not None:
+                    e1.record()
+                    ev_f.append((e0, e1, n))
+                if args.glow and planes_mode:
+                    verts = (eng.radial_path_vertices(prep, sc, W, H, done, n) if radial is not None
+                             else eng.wave_circular_vertices(an, sc, W, H, done, n))
+                    eng.apply_glow(GlowConfig(enabled=True), verts, sc, done, n, planes[0], planes[1], planes[2],
+                                   dev_frames[s][:n])
+                if feather is not None:
+                    eng.feather_blend(prep, an, sc, W, H, done, n, dev_frames[s][:n], with_disc=True)
+                done += n
+                i += 1
+
+        step()
+        ev_f, ev_s = [], []
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.device_steps):
+            step(ev_f, ev_s)
+        barrier()
+        ddt = sharding.max_over_ranks(time.perf_counter() - t1, device if backend == "nccl" else None)
+        roof_dev = kernel_stats(ev_f, frame_bytes)
+        roof_stft = kernel_stats(ev_s, stft_bytes)
+        # `roofline` is the fill kernel at steady clocks (back-to-back launches of the device leg).  Inside the export
+        # steps the same launches are timed too (`fill_in_export_steps`): there the GPU idles ~98 % of the time waiting
+        # for the PCIe link and its clocks ramp down between the 0.24 ms bursts, so the kernel runs slower without
+        # costing the export anything.
+        in_export = roof
+        roof = roof_dev
+        if roof is not None:
+            roof["measured_in"] = "device_leg timed region"
+            roof["fill_in_export_steps"] = ({k: in_export[k] for k in ("achieved", "frac", "avg_launch_ms",
+                                                                        "frames_per_launch")} if in_export else None)
+        device_leg = {"device_fps": round(world * DF * args.device_steps / ddt, 1),
+                      "ms_per_step": round(ddt / args.device_steps * 1e3, 3), "frames_per_gpu_per_step": DF,
+                      "workload": f"configs[4] unit: {args.device_seconds:.0f} s track per GPU, frames stay in HBM "
+                                  f"(2 slots of {DB} frames, overwritten)",
+                      }
+        if roof_stft is not None:
+            roof_stft["kernel"] = (f"stft_frames_kernel<{dtrack.channels}, log=true, bandmax=false, "
+                                   f"samples={'true' if kind.startswith('waveform') else 'false'}>")
+            # what bounds this kernel is the vector ALU, not HBM (traffic = 1.07 x algorithmic, VALU busy 74 %): every
+            # VALU wave-instruction, float64 or not, occupies its SIMD for 4 cycles
+            try:
+                with open(args.isa_json) as fh:
+                    valu = int(json.load(fh)["valu_per_frame"])
+                num_simd = 4 * torch.cuda.get_device_properties(device).multi_processor_count
+                issue_ms = DF / num_simd * valu * F64_ISSUE_NS * 1e-6
+                roof_stft.update({"bound": "valu", "valu_insts_per_frame": valu, "valu_issue_ns_per_inst": F64_ISSUE_NS,
+                                  "issue_roof_ms": round(issue_ms, 4),
+                                  "frac_of_issue_roof": round(issue_ms / roof_stft["avg_launch_ms"], 4),
+                                  "frac_of_hbm_peak": roof_stft["frac"]})
+            except (OSError, ValueError, KeyError):
+                pass
+        del dev_frames, dev_spans, dtrack, daudio
+
     if roof is not None:
         lin = W % 16 == 0 and os.environ.get("AUR_FILL_MODE", "0") != "1"
         roof["kernel"] = ("raster_fill_planes_kernel" if planes_mode else
                           f"raster_fill_lin_kernel<{K}>" if lin else f"raster_fill16_kernel<{K}>")
-    if roof_stft is not None:
-        roof_stft["kernel"] = (f"stft_frames_kernel<{track.channels}, log=true, bandmax=false, "
-                               f"samples={'true' if kind.startswith('waveform') else 'false'}>")
     try:                                               # per-launch HBM bytes from separate --pmc passes, if collected
         with open(args.traffic_json) as fh:
             tj = json.load(fh)
         key = f"{W}x{H}x{B}"
         if roof is not None and not planes_mode and tj.get("raster_fill", {}).get("config") == key:
             roof["traffic"] = tj["raster_fill"]["hbm_bytes_per_launch"]
-        if roof_stft is not None and tj.get("stft", {}).get("frames") == F:
+        if roof_stft is not None and tj.get("stft", {}).get("frames") == roof_stft["frames_per_launch"]:
             roof_stft["traffic"] = tj["stft"]["hbm_bytes_per_launch"]
     except (OSError, ValueError):
         pass
-
-    pcie_fps = pcie_yuv_fps = None
-    if args.pcie_frames > 0 and rank == 0:
-        nf = min(F, args.pcie_frames)
-        for wire in ("rgb24", "yuv420p"):          # the reference's wire format, then the opt-in 1.5 B/px one
-            pipe = FramePipeline(eng, track, args.mode, W, H, frame_begin=0, frame_end=nf, batch_frames=min(64, nf),
-                                 slots=3, wire_format=wire)
-            pipe.analyse()
-            sink = NullSink()
-            torch.cuda.synchronize(device)
-            t1 = time.perf_counter()
-            pipe.run(sink)
-            fps_w = nf / (time.perf_counter() - t1)
-            assert sink.bytes == nf * pipe.frame_bytes
-            if wire == "rgb24":
-                pcie_fps = fps_w
-            else:
-                pcie_yuv_fps = fps_w
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         cpu = cpu_baseline(args)
 
     if rank == 0:
-        value = world * F * args.steps / dt
         out = {
             "metric": "exported frames/sec (whole node) 4K60 spectrum mode at 1/2/4/8 GPUs; STFT GB/s",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 FFT / f32 magnitudes / u8 RGB24",
             "data": "synthetic",
-            "config": {"workload": f"configs[4] unit: {args.seconds:.0f} s {sr} Hz stereo pink-noise track per GPU, "
-                                   f"{args.mode}{' + glow' if args.glow else ''} {W}x{H}@{fps}, {F} frames per GPU per step, frames stay in HBM",
-                       "frames_per_gpu": F, "batch_frames": B, "parallelism": f"time/track shards x{world}"},
+            "config": {"workload": f"{args.seconds:.0f} s {sr} Hz stereo pink-noise track per GPU (resident in HBM), "
+                                   f"{args.mode}{' + glow' if args.glow else ''} {W}x{H}@{fps}, {F} frames per GPU per "
+                                   f"step, every frame read back through a pinned ring into a null sink ({args.wire})",
+                       "frames_per_gpu": F, "batch_frames": B, "ring_slots": args.slots, "wire_format": args.wire,
+                       "parallelism": f"time/track shards x{world}"},
             "stft_gbs": roof_stft["achieved"] if roof_stft else None,
-            "roofline": roof, "roofline_stft": roof_stft, "cpu_baseline": cpu,
-            "pcie_inclusive_fps": round(pcie_fps, 1) if pcie_fps else None,
-            "pcie_inclusive_fps_yuv420p": round(pcie_yuv_fps, 1) if pcie_yuv_fps else None,
+            "roofline": roof,
+            "roofline_pcie": {"bound": "pcie", "achieved": round(link_gbs, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(link_gbs / PCIE_PEAK_GBS, 4), "bytes_per_frame": wire_bytes,
+                              "note": "per GPU: every exported frame crosses the GPU's PCIe Gen5 x16 link once"},
+            "roofline_stft": roof_stft,
+            "device_fps": device_leg["device_fps"] if device_leg else None,
+            "device_leg": device_leg,
+            "yuv420p_leg": ({"fps": round(yuv_fps, 1), "link_gbs": round(yuv_fps * yuv_bytes / 1e9, 2),
+                             "bytes_per_frame": yuv_bytes} if yuv_fps else None),
+            "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -410,6 +410,25 @@ def test_run_pipe_matches_reference_loop(tmp_path):
     assert len(r.times) < 90 and seen[-1] == 100
 
 
+def test_run_pipe_survives_a_chatty_child(tmp_path):
+    """A child that writes more to stderr / stdout than a pipe holds (FFmpeg's statistics over a long encode) while it
+    still reads frames: both pipes are drained during the export, and the tail of stderr reaches the error message."""
+    import sys
+    from aurora_amd.export.exporter import Exporter
+    ex = Exporter("unused.wav", width=64, height=32, fps=30, mode="Spectrum - Linear")
+    chatty = [sys.executable, "-c",
+              "import sys\n"
+              "for i in range(60):\n"
+              "    sys.stdin.buffer.read(64 * 32 * 3)\n"
+              "    sys.stderr.write('x' * 8192 + '\\n'); sys.stderr.flush()\n"
+              "    sys.stdout.write('y' * 8192 + '\\n'); sys.stdout.flush()\n"
+              "sys.stdin.buffer.read(); sys.stderr.write('last words'); sys.exit(5)"]
+    with pytest.raises(RuntimeError) as ei:
+        ex._run_pipe(_DuckRenderer(2.0, (32, 64, 3)), chatty)
+    msg = str(ei.value)
+    assert msg.startswith("ffmpeg failed (exit 5):") and msg.endswith("last words") and len(msg) <= (1 << 16) + 64
+
+
 def test_load_audio_wav_variants_and_ffmpeg_fallback(tmp_path, monkeypatch):
     """Audio ingest (exporter.py:108-113 with `_FFmpegDecodedAudio` :46-81): WAV files are read whole as float32
     [n, C]; anything else goes through `ffmpeg ... -f f32le -ac 1 -ar 48000 -` (a stand-in script here), with the

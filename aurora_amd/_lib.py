@@ -19,7 +19,7 @@ ABI_VERSION = 1
 # every symbol include/aurora_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = (
     "aur_version", "aur_last_error", "aur_device_count", "aur_create", "aur_destroy", "aur_get_window",
-    "aur_stft_frames", "aur_stft_buffer", "aur_log1p_f32", "aur_scan_frames",
+    "aur_stft_frames", "aur_mix_channels", "aur_stft_buffer", "aur_log1p_f32", "aur_scan_frames",
     "aur_spans_spectrum_linear", "aur_spans_particles", "aur_spans_waveform_linear", "aur_raster_spans",
     "aur_raster_work_bytes", "aur_span_summary", "aur_raster_spans_ws", "aur_raster_spans_static",
     "aur_radial_stage1", "aur_radial_ema", "aur_radial_vertices", "aur_envelope_vertices",
@@ -98,6 +98,7 @@ def _declare(lib):
     lib.aur_destroy.argtypes = [vp]
     lib.aur_get_window.argtypes = [vp, vp]
     lib.aur_stft_frames.argtypes = [vp, vp, i64, i32, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.aur_mix_channels.argtypes = [vp, vp, i64, i32, vp, vp]
     lib.aur_stft_buffer.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.aur_log1p_f32.argtypes = [vp, vp, vp, i64, vp]
     lib.aur_scan_frames.argtypes = [vp, vp, vp, i32, C.POINTER(ScanParams), vp, vp, vp, vp, vp, vp]

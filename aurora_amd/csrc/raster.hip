@@ -283,6 +283,29 @@ __global__ __launch_bounds__(256) void raster_fill_kernel(const uint32_t* __rest
     }
 }
 
+// Any width (the reference's UI offers every integer 64..3840, ui/main_window.py:147): one lane per pixel, three byte
+// stores.  Nothing is assumed about alignment or divisibility; it is the slow path of odd sizes (854x480, 101x77).
+template <int K>
+__global__ __launch_bounds__(256) void raster_fill_px_kernel(const uint32_t* __restrict__ spans,
+                                                             const uint32_t* __restrict__ pen_rgb, int W, int H,
+                                                             uint8_t* __restrict__ frames) {
+    const int f = blockIdx.z, row = blockIdx.y;
+    const int px = blockIdx.x * 256 + threadIdx.x;
+    if (px >= W) return;
+    const uint32_t* sp = spans + (long)f * K * W + px;
+    bool lit = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t v = sp[(long)k * W];
+        lit |= ((uint32_t)row - (v & 0xffffu)) < ((v >> 16) - (v & 0xffffu));
+    }
+    const uint32_t c = lit ? (pen_rgb[f] & 0x00ffffffu) : kBg24;
+    uint8_t* dst = frames + (((long)f * H + row) * (long)W + px) * 3;
+    dst[0] = (uint8_t)c;
+    dst[1] = (uint8_t)(c >> 8);
+    dst[2] = (uint8_t)(c >> 16);
+}
+
 // Fast path (W % 16 == 0, 16-byte aligned frames: every standard video size): the frame is walked as uint4
 // (16-byte) columns.  16 bytes hold 5 1/3 RGB pixels, so uint4 column i of a row starts at pixel (16 i) / 3 with
 // byte phase i % 3 and touches 6 pixel columns.  One wave owns 64 consecutive uint4 columns x kRowsPerTask rows:
@@ -512,7 +535,9 @@ __global__ __launch_bounds__(256) void raster_fill_lin_kernel(const uint32_t* __
 
 int check_raster_dims(const char* who, int n_frames, int W, int H) {
     AUR_REQUIRE(n_frames >= 0, "%s: n_frames %d < 0", who, n_frames);
-    AUR_REQUIRE(W >= 160 && W <= 16384 && H >= 16 && H <= 16384, "%s: frame size %dx%d outside [160..16384]x[16..16384]",
+    // W >= 64: the reference UI's smallest export width (ui/main_window.py:147); from 50 columns on no two particles share
+    // a column, which the two span slots per column rely on
+    AUR_REQUIRE(W >= 64 && W <= 16384 && H >= 16 && H <= 16384, "%s: frame size %dx%d outside [64..16384]x[16..16384]",
                 who, W, H);
     AUR_REQUIRE(n_frames <= 65535, "%s: n_frames %d > 65535 per call", who, n_frames);
     return AUR_OK;
@@ -688,14 +713,22 @@ extern "C" int aur_raster_spans(aur_ctx* ctx, const uint32_t* d_spans, int K, co
     if ((rc = check_raster_dims("aur_raster_spans", n_frames, W, H))) return rc;
     if (n_frames == 0) return AUR_OK;
     AUR_REQUIRE(d_spans && d_pen_rgb && d_frames, "aur_raster_spans: null device pointer");
-    AUR_REQUIRE(W % 4 == 0, "aur_raster_spans: width %d must be a multiple of 4", W);
-    AUR_REQUIRE(((uintptr_t)d_frames & 3u) == 0 && ((uintptr_t)d_spans & 15u) == 0 && ((uintptr_t)d_pen_rgb & 3u) == 0,
+    AUR_REQUIRE(((uintptr_t)d_spans & 3u) == 0 && ((uintptr_t)d_pen_rgb & 3u) == 0,
                 "aur_raster_spans: misaligned device pointer");
     const uint32_t* pen = reinterpret_cast<const uint32_t*>(d_pen_rgb);
     hipStream_t st = (hipStream_t)stream;
     if (K != 2 && K != 5) {
         aur_set_error("aur_raster_spans: K=%d unsupported (2 or 5)", K);
         return AUR_EINVAL;
+    }
+    if (W % 4 != 0 || ((uintptr_t)d_frames & 3u) != 0 || ((uintptr_t)d_spans & 15u) != 0) {   // any width, any alignment
+        const dim3 grid((unsigned)((W + 255) / 256), (unsigned)H, (unsigned)n_frames);
+        if (K == 2)
+            hipLaunchKernelGGL(raster_fill_px_kernel<2>, grid, dim3(256), 0, st, d_spans, pen, W, H, d_frames);
+        else
+            hipLaunchKernelGGL(raster_fill_px_kernel<5>, grid, dim3(256), 0, st, d_spans, pen, W, H, d_frames);
+        AUR_CHECK_HIP(hipGetLastError());
+        return AUR_OK;
     }
     if (W % 16 == 0 && ((uintptr_t)d_frames & 15u) == 0) {
         const int nu4 = W * 3 / 16, nchunks = (nu4 + 63) / 64;
@@ -712,7 +745,7 @@ extern "C" int aur_raster_spans(aur_ctx* ctx, const uint32_t* d_spans, int K, co
             if (ctx->fill_nt) AUR_LAUNCH_FILL16(5, true); else AUR_LAUNCH_FILL16(5, false);
         }
 #undef AUR_LAUNCH_FILL16
-    } else {   // generic widths (multiples of 4): 12-byte stores
+    } else {   // widths that are multiples of 4: 12-byte stores
         const dim3 grid((unsigned)((W / 4 + 255) / 256), (unsigned)((H + kRowsPerBlock - 1) / kRowsPerBlock),
                         (unsigned)n_frames);
         if (K == 2)

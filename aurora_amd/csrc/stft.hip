@@ -706,6 +706,35 @@ __global__ __launch_bounds__(256) void log1p_probe_kernel(const float* __restric
     if (i < n) y[i] = log1p_pos(x[i]);
 }
 
+// Mono mix of a track with more than two channels: y.mean(axis=1) of a float32 [n, C] array (exporter.py:233-234) in
+// numpy's own order -- add.reduce over the contiguous axis starts from 0 and, for C < 8, adds the channels left to right;
+// from 8 channels on it keeps eight strided accumulators, joins them as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and adds the
+// remaining C % 8 channels one by one (pairwise_sum, one block: C <= 128) -- then divides by C in float32.
+__global__ __launch_bounds__(256) void mix_channels_kernel(const float* __restrict__ audio, long n_samp, int C,
+                                                           float* __restrict__ mono) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_samp) return;
+    const float* a = audio + i * C;
+    float res;
+    if (C < 8) {
+        res = 0.0f;
+        for (int c = 0; c < C; ++c) res += a[c];
+    } else {
+        float r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        int c = 8;
+        for (; c < C - (C % 8); c += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[k] += a[c + k];
+        }
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; c < C; ++c) res += a[c];
+        res = 0.0f + res;
+    }
+    mono[i] = res / (float)C;
+}
+
 template <int C, bool LOG, bool BM, bool SAMPLES>
 int launch_stft(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int64_t* d_pos, int64_t frame_begin,
                 int n_frames, int hop, float* d_logspec, float* d_flux_sum, float* d_meanabs, float* d_samples,
@@ -760,7 +789,9 @@ extern "C" int aur_stft_frames(aur_ctx* ctx, const float* d_audio, int64_t n_sam
     if (n_frames == 0) return AUR_OK;
     AUR_REQUIRE(d_audio && d_pos && d_flux_sum && d_meanabs, "aur_stft_frames: null device pointer");
     AUR_REQUIRE(n_samples >= 2, "aur_stft_frames: n_samples %lld < 2", (long long)n_samples);
-    AUR_REQUIRE(channels == 1 || channels == 2, "aur_stft_frames: channels %d unsupported (1 or 2)", channels);
+    AUR_REQUIRE(channels == 1 || channels == 2,
+                "aur_stft_frames: channels %d unsupported (1 or 2; mix more channels down with aur_mix_channels first)",
+                channels);
     AUR_REQUIRE(hop >= 1, "aur_stft_frames: hop %d < 1", hop);
     AUR_REQUIRE(frame_begin >= 0, "aur_stft_frames: frame_begin %lld < 0", (long long)frame_begin);
     AUR_REQUIRE(((uintptr_t)d_audio & 7u) == 0 &&
@@ -773,6 +804,21 @@ extern "C" int aur_stft_frames(aur_ctx* ctx, const float* d_audio, int64_t n_sam
                                 d_meanabs, d_samples, d_bandmax, st);
     return launch_stft_c<1>(ctx, d_audio, n_samples, d_pos, frame_begin, n_frames, hop, d_logspec, d_flux_sum,
                             d_meanabs, d_samples, d_bandmax, st);
+}
+
+extern "C" int aur_mix_channels(aur_ctx* ctx, const float* d_audio, int64_t n_samples, int channels, float* d_mono,
+                                void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_samples >= 0, "aur_mix_channels: n_samples %lld < 0", (long long)n_samples);
+    AUR_REQUIRE(channels >= 1 && channels <= 64, "aur_mix_channels: channels %d outside 1..64", channels);
+    if (n_samples == 0) return AUR_OK;
+    AUR_REQUIRE(d_audio && d_mono, "aur_mix_channels: null device pointer");
+    AUR_REQUIRE(n_samples < ((int64_t)1 << 39), "aur_mix_channels: n_samples %lld too large", (long long)n_samples);
+    hipLaunchKernelGGL(mix_channels_kernel, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_audio, (long)n_samples, channels, d_mono);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
 }
 
 extern "C" int aur_stft_buffer(aur_ctx* ctx, const float* d_buffer, float* d_prev_mag, float* d_logspec,

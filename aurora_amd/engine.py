@@ -382,8 +382,15 @@ class HipExportEngine:
         if audio_dev.dtype != torch.float32 or not audio_dev.is_contiguous():
             audio_dev = audio_dev.to(torch.float32).contiguous()
         n, ch = int(audio_dev.shape[0]), int(audio_dev.shape[1])
-        if ch not in (1, 2):
-            raise _lib.AuroraHipError(f"{ch}-channel audio unsupported (mono or stereo)")
+        if ch > 2:
+            # more than two channels (5.1 / 7.1 files): one mono mix per track in numpy's y.mean(axis=1) order
+            # (exporter.py:233-234), then the mono path -- the samples every frame sees are bit-identical
+            if ch > 64:
+                raise _lib.AuroraHipError(f"{ch}-channel audio unsupported (at most 64 channels)")
+            mono = self.empty((max(n, 1), 1), torch.float32)
+            _lib.check(self.lib.aur_mix_channels(self.ctx.handle, _ptr(audio_dev), n, ch, _ptr(mono), self.stream()),
+                       "aur_mix_channels")
+            audio_dev, ch = mono[:n], 1
         hop, total, pos = frame_plan(n, sample_rate, fps)
         if n < 2:       # the kernel loads sample pairs: a 0- or 1-sample file gets zero rows, which is what the
             audio_dev = torch.cat([audio_dev, audio_dev.new_zeros((2 - n, ch))], dim=0)   # reference's padding reads

@@ -13,7 +13,8 @@ launch, rasterised in batches and read back through a pinned ring (``aurora_amd.
 soundfile are optional; there is no CPU rendering fallback.
 
 ``gpu_device`` keeps its reference meaning (an FFmpeg *encoder* id).  The compute device is selected with the
-new key ``hip_device`` (int) in ``view_state``; time sharding with ``hip_frame_range`` = [begin, end).
+new key ``hip_device`` (int) in ``view_state``; time sharding with ``hip_frame_range`` = [begin, end) or
+``hip_shard`` = [rank, world] (``aurora_amd.export.sharded`` starts one such process per GPU).
 """
 from __future__ import annotations
 
@@ -120,6 +121,10 @@ class HipOffscreenRenderer:
         self.audio_path = audio_path
         self.view_state = dict(view_state)
 
+        # sizes the kernels take (the reference UI offers 64..3840 x 64..2160, any integer): checked before the track is
+        # loaded, analysed or FFmpeg is started
+        if not (64 <= self.width <= 16384 and 16 <= self.height <= 16384):
+            raise ValueError(f"frame size {self.width}x{self.height} outside [64..16384]x[16..16384]")
         kind = mode_kind(self.mode)
         if kind not in SUPPORTED_KINDS:
             raise NotImplementedError(f"mode {self.mode!r} is not implemented on the HIP export path yet")
@@ -140,6 +145,10 @@ class HipOffscreenRenderer:
         self.duration = float(self._track.n_samples / self.samplerate)           # exporter.py:113
         self.total_frames = self._track.total_frames
         rng = view_state.get("hip_frame_range")
+        shard = view_state.get("hip_shard")               # [rank, world]: this process renders one time shard
+        if shard and not rng:
+            from ..sharding import frame_range
+            rng = frame_range(self.total_frames, int(shard[1]), int(shard[0]))
         f0, f1 = (int(rng[0]), int(rng[1])) if rng else (0, self.total_frames)
         self.frame_begin, self.frame_end = max(0, f0), min(self.total_frames, f1)
         self._pipe = FramePipeline(self._eng, self._track, self.mode, self.width, self.height, self.sensitivity,
@@ -264,14 +273,9 @@ def list_gpu_export_devices() -> List[Dict[str, str]]:
     return out
 
 
-def build_ffmpeg_cmd(width: int, height: int, fps: int, out_path: str, audio_path: str,
-                     prefer_hevc: bool = False, gpu_device: Optional[str] = None,
-                     input_pix_fmt: str = "rgb24") -> Tuple[List[str], str]:
-    """FFmpeg argv for rawvideo WxH@fps on stdin + the audio file (exporter.py:413-491).  ``input_pix_fmt`` is the
-    reference's "rgb24" unless the renderer was asked for the yuv420p wire format (view_state["hip_wire_format"])."""
-    if input_pix_fmt not in ("rgb24", "yuv420p"):
-        raise ValueError(f"input_pix_fmt {input_pix_fmt!r}")
-    out_path = _ensure_ext(out_path, ".mp4")
+def _encoder_plan(prefer_hevc: bool, gpu_device: Optional[str]):
+    """(ffmpeg, device args, filter, codec, codec flags, output pix_fmt) for an FFmpeg *encoder* id
+    (exporter.py:422-483): hardware family when its encoder exists, else libx264."""
     ffmpeg = _ffmpeg_bin()
     enc = _ffmpeg_encoders(ffmpeg)
     system = platform.system()
@@ -283,8 +287,6 @@ def build_ffmpeg_cmd(width: int, height: int, fps: int, out_path: str, audio_pat
         choices = list_gpu_export_devices()
         dev = choices[0]["id"] if choices else ""
 
-    argv: List[str] = [ffmpeg, "-y", "-f", "rawvideo", "-pix_fmt", input_pix_fmt, "-s", f"{width}x{height}",
-                       "-r", str(int(fps)), "-i", "pipe:0", "-i", audio_path]
     fam = dev.split(":", 1)[0] if dev else ""
     arg = dev.split(":", 1)[1] if ":" in dev else ""
     if fam == "videotoolbox":            # exact id, macOS only; a missing encoder is an error, not a fallback (:446-448)
@@ -292,7 +294,7 @@ def build_ffmpeg_cmd(width: int, height: int, fps: int, out_path: str, audio_pat
     else:                                # "<family>:<arg>" and at least one encoder of the family, else libx264 (:450-476)
         usable = (fam in _HW and ":" in dev and (_HW[fam][0] in enc or _HW[fam][1] in enc)
                   and (fam != "vaapi" or system == "Linux"))
-    pix_out, vfilter = "yuv420p", None
+    pix_out, vfilter, dev_args = "yuv420p", None, []
     if usable:
         h264, hevc, flags = _HW[fam]
         codec = hevc if (prefer_hevc and hevc in enc) else h264
@@ -306,13 +308,48 @@ def build_ffmpeg_cmd(width: int, height: int, fps: int, out_path: str, audio_pat
                 idx = 0
             vflags = ["-gpu", str(idx)] + vflags
         elif fam == "vaapi":
-            argv += ["-vaapi_device", arg]
+            dev_args = ["-vaapi_device", arg]
             vfilter, pix_out = "format=nv12,hwupload", "nv12"
     else:
         codec, vflags = "libx264", ["-preset", "veryfast", "-crf", "20"]
+    return ffmpeg, dev_args, vfilter, codec, vflags, pix_out
+
+
+def _check_pix_fmt(input_pix_fmt):
+    if input_pix_fmt not in ("rgb24", "yuv420p"):
+        raise ValueError(f"input_pix_fmt {input_pix_fmt!r}")
+
+
+def build_ffmpeg_cmd(width: int, height: int, fps: int, out_path: str, audio_path: str,
+                     prefer_hevc: bool = False, gpu_device: Optional[str] = None,
+                     input_pix_fmt: str = "rgb24") -> Tuple[List[str], str]:
+    """FFmpeg argv for rawvideo WxH@fps on stdin + the audio file (exporter.py:413-491).  ``input_pix_fmt`` is the
+    reference's "rgb24" unless the renderer was asked for the yuv420p wire format (view_state["hip_wire_format"])."""
+    _check_pix_fmt(input_pix_fmt)
+    out_path = _ensure_ext(out_path, ".mp4")
+    ffmpeg, dev_args, vfilter, codec, vflags, pix_out = _encoder_plan(prefer_hevc, gpu_device)
+    argv: List[str] = [ffmpeg, "-y", "-f", "rawvideo", "-pix_fmt", input_pix_fmt, "-s", f"{width}x{height}",
+                       "-r", str(int(fps)), "-i", "pipe:0", "-i", audio_path]
+    argv += dev_args
     if vfilter:
         argv += ["-vf", vfilter]
     argv += ["-c:v", codec, *vflags, "-pix_fmt", pix_out, "-c:a", "aac", "-b:a", "192k", "-shortest", out_path]
+    return argv, input_pix_fmt
+
+
+def build_ffmpeg_segment_cmd(width: int, height: int, fps: int, out_path: str, prefer_hevc: bool = False,
+                             gpu_device: Optional[str] = None, input_pix_fmt: str = "rgb24") -> Tuple[List[str], str]:
+    """The same encode for one time shard of a multi-GPU export (aurora_amd.export.sharded): video only (``-an``); the
+    supervisor joins the segments and muxes the audio.  Not in the reference, which encodes in one process."""
+    _check_pix_fmt(input_pix_fmt)
+    out_path = _ensure_ext(out_path, ".mp4")
+    ffmpeg, dev_args, vfilter, codec, vflags, pix_out = _encoder_plan(prefer_hevc, gpu_device)
+    argv: List[str] = [ffmpeg, "-y", "-f", "rawvideo", "-pix_fmt", input_pix_fmt, "-s", f"{width}x{height}",
+                       "-r", str(int(fps)), "-i", "pipe:0"]
+    argv += dev_args
+    if vfilter:
+        argv += ["-vf", vfilter]
+    argv += ["-c:v", codec, *vflags, "-pix_fmt", pix_out, "-an", out_path]
     return argv, input_pix_fmt
 
 
@@ -382,9 +419,13 @@ class Exporter:
     def render_to_file(self, out_path, progress_cb=None):
         renderer = self.make_renderer()
         logger.info("Export using HIP renderer on MI355X (device %s)", self.view_state.get("hip_device", 0))
-        cmd, _ = build_ffmpeg_cmd(self.width, self.height, self.fps, out_path, self.audio_path,
-                                  prefer_hevc=self.prefer_hevc, gpu_device=self.gpu_device,
-                                  input_pix_fmt=getattr(renderer, "wire_format", "rgb24"))
+        wire = getattr(renderer, "wire_format", "rgb24")
+        if self.view_state.get("hip_segment"):           # one shard of a multi-GPU export: video-only segment
+            cmd, _ = build_ffmpeg_segment_cmd(self.width, self.height, self.fps, out_path, prefer_hevc=self.prefer_hevc,
+                                              gpu_device=self.gpu_device, input_pix_fmt=wire)
+        else:
+            cmd, _ = build_ffmpeg_cmd(self.width, self.height, self.fps, out_path, self.audio_path,
+                                      prefer_hevc=self.prefer_hevc, gpu_device=self.gpu_device, input_pix_fmt=wire)
         return self._run_pipe(renderer, cmd, progress_cb=progress_cb)
 
     def render_to_sink(self, sink, progress_cb=None):

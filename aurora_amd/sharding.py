@@ -38,12 +38,16 @@ def max_over_ranks(seconds: float, device=None) -> float:
     return float(t.item())
 
 
-def gather_segments_in_order(segment: bytes, dst: int = 0):
-    """Final gather of the export: every rank hands its rendered segment (or its digest) to ``dst``, which
-    receives them in rank order = frame order.  Returns the list on ``dst`` and None elsewhere."""
+def gather_digests_in_order(digest: str, n_bytes: int, dst: int = 0):
+    """The only exchange of a time-sharded export between ranks that share a process group: every rank writes its segment
+    to its own file (or its own FFmpeg) and hands ``dst`` a (rank, sha256 hex digest, byte count) record -- never the
+    frames themselves -- so ``dst`` can verify the segments it joins in rank order = frame order.  Returns the records
+    on ``dst`` and None elsewhere.  (``aurora_amd.export.sharded`` needs no process group at all: its children are
+    independent processes and the supervisor reads the segment files.)"""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return [segment]
+        return [(0, str(digest), int(n_bytes))]
+    rec = (dist.get_rank(), str(digest), int(n_bytes))
     out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
-    dist.gather_object(segment, out, dst=dst)
+    dist.gather_object(rec, out, dst=dst)
     return out

@@ -79,7 +79,8 @@ int  aur_get_window(aur_ctx* ctx, float* h_window /*[2048]*/);
  * frame_begin is rebuilt from the audio itself (time-shard halo), so any frame range gives the same
  * values as a run from frame 0.
  *
- * d_audio  : float32 [n_samples, channels] interleaved (soundfile layout); channels must be 1 or 2.
+ * d_audio  : float32 [n_samples, channels] interleaved (soundfile layout); channels must be 1 or 2 (more: see
+ *            aur_mix_channels).
  * d_pos    : int64 [n_track_frames] sample position of EVERY frame of the track (exporter.py:230),
  *            computed on the host in float64; entries frame_begin-2 .. frame_begin+n_frames-1 are read.
  * hop      : max(1, int(sr/fps)) (exporter.py:229).
@@ -89,6 +90,14 @@ int aur_stft_frames(aur_ctx* ctx,
                     const int64_t* d_pos, int64_t frame_begin, int n_frames, int hop,
                     float* d_logspec, float* d_flux_sum, float* d_meanabs,
                     float* d_samples, float* d_bandmax, void* stream);
+
+/* Mono mix of a track with any channel count: d_mono[i] = mean(d_audio[i, :]) in float32, evaluated in the order numpy's
+ * `y.mean(axis=1)` uses (export/exporter.py:233-234): left to right from 0 below 8 channels, eight strided accumulators
+ * joined pairwise from 8 on, divided by the channel count.  aur_stft_frames takes 1 or 2 channels itself (its loads are
+ * specialised for them); tracks with more (5.1, 7.1 files) are mixed once per track with this call and analysed as mono,
+ * which gives the same samples bit for bit.  d_audio: float32 [n_samples, channels]; d_mono: float32 [n_samples];
+ * 1 <= channels <= 64. */
+int aur_mix_channels(aur_ctx* ctx, const float* d_audio, int64_t n_samples, int channels, float* d_mono, void* stream);
 
 /* One streaming Analyzer.compute step (audio/analysis.py:25-33) for callers that keep Analyzer.buffer
  * themselves (the realtime caller audio/input.py:276-293 and the drop-in Analyzer.compute):
@@ -135,7 +144,8 @@ int aur_scan_frames(aur_ctx* ctx, const float* d_meanabs, const float* d_flux_su
 /* ---- rasteriser -------------------------------------------------------------------------------- */
 
 /* Column spans: uint32 [n_frames, K, W]; element = r0 | (r1 << 16), a half-open lit row interval
- * [r0, r1) of that pixel column (0 = empty).  W, H <= 16384; W >= 160.                              */
+ * [r0, r1) of that pixel column (0 = empty).  64 <= W <= 16384 (any integer: the reference UI offers 64..3840),
+ * 16 <= H <= 16384.                                                                                 */
 
 /* `_draw_spectrum` linear branch (rt_widget.py:934-940, :982-988): 80 vertical width-2 lines. K = 2. */
 int aur_spans_spectrum_linear(aur_ctx* ctx, const float* d_logspec /*[F,1025]*/, const double* d_energy /*[F]*/,

@@ -562,6 +562,15 @@ def main():
                           shadow_enabled=True, radial_fill_enabled=True, radial_fill_threshold=0.0), [0, 3],
                      sensitivity=2.5)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "multichannel":   # adds the analysis_*ch* fixtures only
+        _install_stand_ins()
+        sys.path.insert(0, REF)
+        # y.mean(axis=1) over more than two channels (exporter.py:233-234): 5.1 and 3-channel tracks, 9 channels for
+        # numpy's 8-accumulator pairwise order
+        capture_analysis("pink_48k_60_6ch", "pink", 20000, 48000, 60, 6)
+        capture_analysis("pink_44k1_30_3ch", "pink", 15000, 44100, 30, 3, sensitivity=1.5)
+        capture_analysis("pink_48k_60_9ch", "pink", 9000, 48000, 60, 9)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "shadow":         # adds the shadow_* fixtures only
         _install_stand_ins()
         sys.path.insert(0, REF)

@@ -154,7 +154,8 @@ MODES = ["Spectrum - Linear", "Waveform - Linear", "Particles"]
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("size", [(1280, 720), (1920, 1080), (3840, 2160), (1000, 562)])
+@pytest.mark.parametrize("size", [(1280, 720), (1920, 1080), (3840, 2160), (1000, 562), (854, 480), (101, 77), (64, 64),
+                                  (3839, 2159)])
 def test_raster_bit_exact_given_same_analysis(eng, mode, size):
     from aurora_amd import synth
     from aurora_amd.pipeline import FramePipeline
@@ -341,12 +342,40 @@ def test_abi_rejects_bad_arguments(eng):
     lib, h = eng.lib, eng.ctx.handle
     assert lib.aur_raster_spans(h, C.c_void_p(16), 3, C.c_void_p(16), 1, 1280, 720, C.c_void_p(16), None) == -1
     assert b"K=3" in lib.aur_last_error()
-    assert lib.aur_raster_spans(h, C.c_void_p(16), 2, C.c_void_p(16), 1, 1282, 720, C.c_void_p(16), None) == -1
+    # (a width that is not a multiple of 4 is accepted since round 2: per-pixel fill; sizes outside the limits are not)
+    assert lib.aur_raster_spans(h, C.c_void_p(16), 2, C.c_void_p(16), 1, 63, 720, C.c_void_p(16), None) == -1
+    assert lib.aur_raster_spans(h, C.c_void_p(16), 2, C.c_void_p(18), 1, 1280, 720, C.c_void_p(16), None) == -1   # pen misaligned
     assert lib.aur_stft_frames(h, C.c_void_p(16), 100, 3, C.c_void_p(16), 0, 1, 800, None, C.c_void_p(16),
                                C.c_void_p(16), None, None, None) == -1
     assert b"channels" in lib.aur_last_error()
     hh = C.c_void_p()
     assert lib.aur_create(99, C.byref(hh)) == -1
+    # the edges of the raster limits: accepted on one side (a launch on real buffers), rejected on the other
+    import torch
+    for W, H, ok in ((64, 16, True), (63, 16, False), (64, 15, False), (16384, 16, True), (16385, 16, False)):
+        spans = torch.zeros((1, 2, W), dtype=torch.int32, device=eng.device)
+        pen = torch.zeros((1, 4), dtype=torch.uint8, device=eng.device)
+        out = torch.empty((1, max(H, 1), W, 3), dtype=torch.uint8, device=eng.device)
+        rc = lib.aur_raster_spans(h, C.c_void_p(spans.data_ptr()), 2, C.c_void_p(pen.data_ptr()), 1, W, H,
+                                  C.c_void_p(out.data_ptr()), eng.stream())
+        assert (rc == 0) == ok, (W, H, rc, lib.aur_last_error())
+        if ok:
+            assert bool((out.view(-1, 3) == torch.tensor([13, 13, 18], dtype=torch.uint8, device=eng.device)).all())
+    # frames per call: 65535 is the last accepted count (checked on the span kernel, whose output is small)
+    ls = torch.zeros((65536, 1025), dtype=torch.float32, device=eng.device)
+    en = torch.zeros((65536,), dtype=torch.float64, device=eng.device)
+    sp = torch.empty((65536, 2, 64), dtype=torch.int32, device=eng.device)
+    args = (C.c_void_p(ls.data_ptr()), C.c_void_p(en.data_ptr()))
+    assert lib.aur_spans_spectrum_linear(h, *args, 65535, 64, 16, C.c_void_p(sp.data_ptr()), eng.stream()) == 0
+    assert lib.aur_spans_spectrum_linear(h, *args, 65536, 64, 16, C.c_void_p(sp.data_ptr()), eng.stream()) == -1
+    assert b"65535" in lib.aur_last_error()
+    torch.cuda.synchronize()
+    # a batch whose 16-byte columns do not fit 31-bit indices leaves the linear fill for the row-tile kernel instead of
+    # overflowing (raster_lin_ok): 5 frames of 16384 x 16384 would need 7.5 G columns -- exercised at the boundary
+    # through the work-area size only (allocating such frames is not something a test should do)
+    need = C.c_size_t()
+    assert lib.aur_raster_work_bytes(5, 16384, C.byref(need)) == 0 and need.value == 5 * (3072 * 8 + 16384 * 4)
+    assert lib.aur_raster_work_bytes(1, 16385, C.byref(need)) == -1
 
 
 def test_worker_end_to_end_raw_stream(eng, tmp_path, capsys):

@@ -156,6 +156,47 @@ def test_worker_setup_errors(capsys, tmp_path):
     assert "Invalid config JSON" in json.loads(capsys.readouterr().out.strip())["message"]
 
 
+def test_worker_maps_config_keys_and_failures(capsys, tmp_path, monkeypatch):
+    """Config keys -> Exporter arguments; a missing required key or a failing export is exit 1 with an
+    error message, progress lines are integers."""
+    from aurora_amd.export import exporter, worker
+    cfg = {"audio_path": "a.wav", "out_path": "o.mp4", "width": "1280", "height": 720.0, "fps": 30, "mode": "Spectrum - Linear",
+           "color": [0.1, 0.2, 0.3], "sensitivity": "1.5"}
+    kw = worker.exporter_kwargs(cfg)
+    assert kw == {"audio_path": "a.wav", "width": 1280, "height": 720, "fps": 30, "mode": "Spectrum - Linear",
+                  "color": (0.1, 0.2, 0.3), "sensitivity": 1.5, "prefer_hevc": False, "view_state": {}, "gpu_device": ""}
+    kw = worker.exporter_kwargs(dict(cfg, prefer_hevc=1, view_state=None, gpu_device=None))
+    assert kw["prefer_hevc"] is True and kw["view_state"] == {} and kw["gpu_device"] == ""
+    calls = []
+
+    class FakeExporter:
+        def __init__(self, **kw):
+            calls.append(kw)
+
+        def render_to_file(self, out_path, progress_cb=None):
+            progress_cb(0)
+            progress_cb(49.9)
+            if out_path == "fail.mp4":
+                raise RuntimeError("ffmpeg failed (exit 1):\nnope")
+            progress_cb(100)
+
+    monkeypatch.setattr(exporter, "Exporter", FakeExporter)
+    p = tmp_path / "cfg.json"
+    p.write_text(json.dumps(cfg))
+    assert worker.main(["worker.py", str(p)]) == 0
+    out = [json.loads(l) for l in capsys.readouterr().out.strip().splitlines()]
+    assert out == [{"type": "progress", "pct": 0}, {"type": "progress", "pct": 49}, {"type": "progress", "pct": 100},
+                   {"type": "done"}]
+    p.write_text(json.dumps(dict(cfg, out_path="fail.mp4")))
+    assert worker.main(["worker.py", str(p)]) == 1
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1]) == {"type": "error",
+                                                                          "message": "ffmpeg failed (exit 1):\nnope"}
+    del cfg["fps"]
+    p.write_text(json.dumps(cfg))
+    assert worker.main(["worker.py", str(p)]) == 1                      # KeyError inside the export block
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["type"] == "error"
+
+
 def test_synth_shapes():
     a = synth.sweep(4410, 44100)
     b = synth.pink(4800, 2)

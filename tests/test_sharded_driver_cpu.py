@@ -1,0 +1,165 @@
+"""The multi-GPU export driver (aurora_amd/export/sharded.py) on CPU: process supervision, shard configs, ordered join,
+progress aggregation, failure handling and the many-tracks lanes, with stand-in worker / FFmpeg child processes (the
+real children need a GPU: tests/test_gpu_sharded.py)."""
+import json
+import os
+import stat
+import sys
+import textwrap
+
+import pytest
+
+from aurora_amd import sharding
+from aurora_amd.export import sharded
+
+# A stand-in for `python -m aurora_amd.export.worker cfg.json`: frame f of the track is the byte (f % 251) repeated
+# `frame_bytes` times; it writes the frames of its shard (or the whole track) the way the real worker would.
+FAKE_WORKER = textwrap.dedent('''
+    import json, os, sys, time
+    cfg = json.load(open(sys.argv[1]))
+    vs = cfg.get("view_state") or {}
+    total, fb = int(cfg["fake_total_frames"]), int(cfg["fake_frame_bytes"])
+    rank, world = vs.get("hip_shard") or [0, 1]
+    base, extra = divmod(total, world)
+    a = rank * base + min(rank, extra)
+    b = a + base + (1 if rank < extra else 0)
+    if cfg.get("fake_fail_rank") == rank:
+        print(json.dumps({"type": "error", "message": "boom on rank %d" % rank}), flush=True)
+        sys.exit(1)
+    if cfg.get("fake_hang_rank") == rank:
+        time.sleep(600)
+    out = cfg.get("hip_raw_out") or cfg["out_path"]
+    with open(out, "wb") as fh:
+        for f in range(a, b):
+            fh.write(bytes([f % 251]) * fb)
+            if f % 7 == 0:
+                print(json.dumps({"type": "progress", "pct": int(f * 100 / total)}), flush=True)
+    with open(out + ".meta", "w") as fh:
+        json.dump({"device": vs.get("hip_device"), "segment": bool(vs.get("hip_segment")), "pid": os.getpid()}, fh)
+    print(json.dumps({"type": "progress", "pct": 100}), flush=True)
+    print(json.dumps({"type": "done"}), flush=True)
+''')
+
+# A stand-in FFmpeg for the join: `-f concat -i list.txt ... out` concatenates the listed files.
+FAKE_FFMPEG = textwrap.dedent('''\
+    #!%s
+    import re, sys
+    a = sys.argv[1:]
+    if "-encoders" in a:
+        sys.exit(0)
+    assert a[a.index("-f") + 1] == "concat", a
+    lst = a[a.index("-i") + 1]
+    with open(a[-1], "wb") as out:
+        for line in open(lst):
+            out.write(open(re.match(r"file '(.*)'", line.strip()).group(1), "rb").read())
+''') % sys.executable
+
+
+@pytest.fixture
+def fake_worker(tmp_path):
+    p = tmp_path / "fake_worker.py"
+    p.write_text(FAKE_WORKER)
+    return [sys.executable, str(p)]
+
+
+def _cfg(tmp_path, total=53, fb=16, **extra):
+    c = {"audio_path": "a.wav", "out_path": str(tmp_path / "out.mp4"), "width": 4, "height": 2, "fps": 30,
+         "mode": "Spectrum - Linear", "color": [0.2, 0.8, 1.0], "sensitivity": 1.0, "view_state": {"hip_gpus": 3},
+         "fake_total_frames": total, "fake_frame_bytes": fb}
+    c.update(extra)
+    return c
+
+
+def _expected(total, fb):
+    return b"".join(bytes([f % 251]) * fb for f in range(total))
+
+
+def test_shard_configs_are_rank_ordered_ranges(tmp_path):
+    cfg = _cfg(tmp_path, hip_raw_out=str(tmp_path / "frames.rgb"))
+    cs = sharded.shard_configs(cfg, 4, devices=[0, 1])
+    assert [c["view_state"]["hip_shard"] for c in cs] == [[r, 4] for r in range(4)]
+    assert [c["view_state"]["hip_device"] for c in cs] == [0, 1, 0, 1]
+    assert all("hip_gpus" not in c["view_state"] and "hip_segment" not in c["view_state"] for c in cs)
+    assert cs[2]["hip_raw_out"].endswith("frames.seg002.rgb")
+    enc = sharded.shard_configs(_cfg(tmp_path), 2)
+    assert enc[1]["out_path"].endswith("out.seg001.mp4") and enc[1]["view_state"]["hip_segment"] is True
+    assert cfg["view_state"] == {"hip_gpus": 3}                         # the caller's config is not modified
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_raw_segments_join_to_the_unsharded_stream(tmp_path, fake_worker, world):
+    total, fb = 53, 16
+    raw = tmp_path / "frames.rgb"
+    seen = []
+    report = sharded.export_sharded(_cfg(tmp_path, total, fb, hip_raw_out=str(raw)), world, seen.append,
+                                    worker_cmd=fake_worker, devices=[0])
+    assert raw.read_bytes() == _expected(total, fb)
+    sizes = [n for _, n, _ in report]
+    want = [fb * (b - a) for a, b in (sharding.frame_range(total, world, r) for r in range(world))]
+    assert sizes == want and len({d for _, _, d in report}) == len(report)
+    assert not list(tmp_path.glob("frames.seg*.rgb"))                   # segments removed after the join
+    assert seen[-1] == 100 and seen == sorted(seen) and len(set(seen)) == len(seen)
+
+
+def test_encoded_segments_are_joined_by_ffmpeg_concat(tmp_path, fake_worker, monkeypatch):
+    ff = tmp_path / "ffmpeg"
+    ff.write_text(FAKE_FFMPEG)
+    ff.chmod(ff.stat().st_mode | stat.S_IXUSR)
+    monkeypatch.setenv("AURORA_FFMPEG", str(ff))
+    cmd = sharded.build_ffmpeg_concat_cmd("l.txt", "a.wav", "o.mp4")
+    assert cmd == [str(ff), "-y", "-f", "concat", "-safe", "0", "-i", "l.txt", "-i", "a.wav", "-c:v", "copy",
+                   "-c:a", "aac", "-b:a", "192k", "-shortest", "o.mp4"]
+    sharded.export_sharded(_cfg(tmp_path, 40, 8), 3, None, worker_cmd=fake_worker, devices=[0], keep_segments=True)
+    assert (tmp_path / "out.mp4").read_bytes() == _expected(40, 8)
+    metas = [json.load(open(str(tmp_path / f"out.seg{r:03d}.mp4") + ".meta")) for r in range(3)]
+    assert all(m["segment"] for m in metas) and len({m["pid"] for m in metas}) == 3   # one process per shard
+
+
+def test_segment_command_is_the_reference_encode_without_audio(tmp_path, monkeypatch):
+    from aurora_amd.export import exporter
+    ff = tmp_path / "ffmpeg"
+    ff.write_text(FAKE_FFMPEG)
+    ff.chmod(ff.stat().st_mode | stat.S_IXUSR)
+    monkeypatch.setenv("AURORA_FFMPEG", str(ff))
+    full, _ = exporter.build_ffmpeg_cmd(3840, 2160, 60, "o.mp4", "a.wav")
+    seg, _ = exporter.build_ffmpeg_segment_cmd(3840, 2160, 60, "o.seg000.mp4")
+    i = full.index("a.wav")
+    assert seg[:i - 1] == full[:i - 1]                                   # same raw-video input
+    j = full.index("-c:a")
+    assert seg[i - 1:-2] == full[i + 1:j] and seg[-2:] == ["-an", "o.seg000.mp4"]   # same encoder arguments
+
+
+def test_a_failing_shard_stops_the_others(tmp_path, fake_worker):
+    cfg = _cfg(tmp_path, hip_raw_out=str(tmp_path / "frames.rgb"), fake_fail_rank=1, fake_hang_rank=2)
+    with pytest.raises(RuntimeError) as ei:
+        sharded.export_sharded(cfg, 3, None, worker_cmd=fake_worker, devices=[0])
+    assert "boom on rank 1" in str(ei.value)
+    assert not (tmp_path / "frames.rgb").exists()
+
+
+def test_many_tracks_are_dealt_over_gpu_lanes(tmp_path, fake_worker):
+    cfgs = [_cfg(tmp_path, 10 + k, 4, hip_raw_out=str(tmp_path / f"t{k}.rgb")) for k in range(7)]
+    seen = []
+    assert sharded.export_tracks(cfgs, 3, seen.append, worker_cmd=fake_worker) == 7
+    for k in range(7):
+        assert (tmp_path / f"t{k}.rgb").read_bytes() == _expected(10 + k, 4)
+        assert json.load(open(str(tmp_path / f"t{k}.rgb") + ".meta"))["device"] == k % 3     # track k on GPU k mod 3
+    assert seen[-1] == 100
+
+
+def test_cli_and_worker_dispatch(tmp_path, fake_worker, capsys, monkeypatch):
+    cfg = _cfg(tmp_path, hip_raw_out=str(tmp_path / "frames.rgb"))
+    p = tmp_path / "cfg.json"
+    p.write_text(json.dumps(cfg))
+    monkeypatch.setattr(sharded, "default_worker_cmd", lambda: fake_worker)
+    assert sharded.main(["sharded", str(p), "--gpus", "2", "--devices", "0"]) == 0
+    lines = [json.loads(l) for l in capsys.readouterr().out.strip().splitlines()]
+    assert lines[-1] == {"type": "done"} and lines[-2] == {"type": "progress", "pct": 100}
+    assert (tmp_path / "frames.rgb").read_bytes() == _expected(53, 16)
+    # the reference's entry point with view_state["hip_gpus"] > 1 supervises instead of rendering
+    from aurora_amd.export import worker
+    os.remove(tmp_path / "frames.rgb")
+    assert worker.main(["worker.py", str(p)]) == 0
+    assert (tmp_path / "frames.rgb").read_bytes() == _expected(53, 16)
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1]) == {"type": "done"}
+    assert sharded.main(["sharded", str(tmp_path / "missing.json"), "--gpus", "2"]) == 2

@@ -1,5 +1,6 @@
-"""N > 1 host path on CPU: two gloo ranks shard a track by time, 'render' their ranges with the oracle and the
-final gather reassembles the unsharded byte stream; the job time is the max over ranks."""
+"""N > 1 host path on CPU: two gloo ranks shard a track by time, 'render' their ranges with the oracle into per-rank
+segment files, exchange digests only, and rank 0 joins the files in rank order into the unsharded byte stream; the job
+time is the max over ranks."""
 import hashlib
 import os
 import socket
@@ -24,9 +25,10 @@ def test_frame_ranges_tile_the_track():
         sharding.frame_range(10, 2, 2)
 
 
-def _rank_main(rank, world, port, q):
+def _rank_main(rank, world, port, q, tmpdir):
     import torch.distributed as dist
     from aurora_amd import synth
+    from aurora_amd.export import sharded
     from oracle import analysis_ref as A
     from oracle import raster_ref as R
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,26 +41,36 @@ def _rank_main(rank, world, port, q):
         pen, _ = A.amp_to_color_track(ref["energy"])
         F = ref["samples"].shape[0]
         a, b = sharding.frame_range(F, world, rank)
-        seg = b"".join(R.render_frame("Spectrum - Linear", ref["samples"][f], ref["logspec"][f],
-                                      float(ref["energy"][f]), pen[f], W, H).tobytes() for f in range(a, b))
-        parts = sharding.gather_segments_in_order(seg)
+        seg_path = sharded.segment_path(os.path.join(tmpdir, "frames.rgb"), rank)
+        with open(seg_path, "wb") as fh:
+            for f in range(a, b):
+                fh.write(R.render_frame("Spectrum - Linear", ref["samples"][f], ref["logspec"][f],
+                                        float(ref["energy"][f]), pen[f], W, H).tobytes())
+        recs = sharding.gather_digests_in_order(sharded.file_digest(seg_path), os.path.getsize(seg_path))
         slow = sharding.max_over_ranks(1.0 + rank)
+        dist.barrier()                                            # every segment file is complete
         if rank == 0:
-            whole = b"".join(R.render_frame("Spectrum - Linear", ref["samples"][f], ref["logspec"][f],
-                                            float(ref["energy"][f]), pen[f], W, H).tobytes() for f in range(F))
-            q.put((hashlib.sha256(b"".join(parts)).hexdigest() == hashlib.sha256(whole).hexdigest(),
-                   [len(p) for p in parts], slow, F))
+            assert [r[0] for r in recs] == list(range(world))
+            paths = [sharded.segment_path(os.path.join(tmpdir, "frames.rgb"), r) for r in range(world)]
+            joined = os.path.join(tmpdir, "frames.rgb")
+            report = sharded.join_raw_segments(paths, joined)
+            ok = [(d, n) for _, n, d in report] == [(r[1], r[2]) for r in recs]
+            whole = hashlib.sha256()
+            for f in range(F):
+                whole.update(R.render_frame("Spectrum - Linear", ref["samples"][f], ref["logspec"][f],
+                                            float(ref["energy"][f]), pen[f], W, H).tobytes())
+            q.put((ok and sharded.file_digest(joined) == whole.hexdigest(), [r[2] for r in recs], slow, F))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_time_shards_reassemble():
+def test_two_rank_time_shards_reassemble(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
     for p in procs:
         p.start()
     same, sizes, slow, F = q.get(timeout=120)

@@ -33,12 +33,13 @@
 // Contraction is disabled for the whole library (-ffp-contract=off); fma is used explicitly where wanted.
 #include "common.h"
 
-// Spectrum stores: plain by default (-DAUR_STFT_NT=1 builds the non-temporal variant for A/B runs).
-#if AUR_STFT_NT
-#define AUR_STFT_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
-#define AUR_STFT_ST(ptr, val) (*(ptr) = (val))
+// Spectrum stores: plain by default (-DAUR_STFT_NT=1 builds the non-temporal variant for A/B runs: aux bit 1 = slc).
+#ifndef AUR_STFT_NT
+#define AUR_STFT_NT 0
 #endif
+__device__ __forceinline__ void aur_buf_st(float v, const __amdgpu_buffer_rsrc_t rs, int byte_offset) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, byte_offset, 0, AUR_STFT_NT ? 2 : 0);
+}
 
 #include <type_traits>
 
@@ -157,60 +158,53 @@ __device__ __forceinline__ float wave_max_pos(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// 16 / 8 bytes of interleaved samples at their natural alignment (frame positions are arbitrary sample offsets)
-struct __attribute__((aligned(8))) f4a8 {
-    float x, y, z, w;
-};
-struct __attribute__((aligned(4))) f2a4 {
-    float x, y;
-};
+// Raw buffer resources (V#) for the track reads and the per-frame stores.  gfx950 is a GFX9-family part: word 3 =
+// DATA_FORMAT 32 (the value composable_kernel uses for gfx90a / gfx94x / gfx950).  A buffer access beyond num_records
+// reads 0 / is dropped, checked per dword, which is exactly the reference's zero padding -- see issue_block.
+constexpr int kRsrcWord3 = 0x00020000;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // One 1024-sample analysis block of frame `fi` (exporter.py:230-237) in the lane layout of the FFT:
 // blk[2jj], blk[2jj+1] = samples[2*lane + 128*jj], samples[2*lane + 128*jj + 1].
 // Two phases, so that the loads can fly while another frame is being transformed: issue_block requests the raw
-// interleaved samples, mix_block (mono mean + zero padding) is the first thing that waits for them.
-// Frames whose whole 1024-sample read window lies inside the track (all but the last one or two) take eight
-// unconditional 16-byte loads issued back to back; the last frames clamp every sample index to the track instead.
-// Zero padding (samples >= nvalid) is a select against r = nvalid - 2*lane, so nothing per-jj stays in registers.
+// interleaved samples, mix_block (mono mean) is the first thing that waits for them.
 template <int C>
 struct RawBlock {
-    float q[8][2 * C];   // jj -> two consecutive samples (C channels each) starting at sample min(s, n_samp - 2)
-    int r;               // sample 128*jj (+1) of this lane is inside the read window iff 128*jj (+1) < r
-    int shifted;         // bit jj: the pair was clamped one sample down (s == n_samp - 1): sample s is its second half
+    float q[8][2 * C];   // jj -> two consecutive samples (C channels each)
 };
 
-// Branch-free: eight unconditional loads of two samples each (16 bytes for stereo).  A pair that would run past
-// the end of the track is moved down by one sample (`shifted`; its second sample is then outside the read window
-// anyway), a pair entirely outside reads the last two samples and is dropped by the window test; frames before the
-// track start (fi < 0: Analyzer.buffer is zero, analysis.py:14) read frame 0's block with an empty window.
-// No control flow joins behind the loads, so nothing touches the data before mix_block.  Needs n_samp >= 2.
+// The frame's read window [pos, pos + nvalid), nvalid = min(hop, 1024, n_samp - pos) (a short read at the end of the
+// file, exporter.py:231-236), becomes the buffer resource itself: base = &audio[pos], num_records = nvalid samples.
+// Every sample of the block beyond the window -- the 224 zeros of an 800-sample hop, the tail of the last frames, the
+// whole block in front of the track start (fi < 0: Analyzer.buffer is zero, analysis.py:14) -- is then out of range and
+// loads as 0 without a compare, a select or a clamped address in the vector ALU: the resource is four scalar registers
+// built by the scalar ALU from the wave-uniform pos[fi].  Eight unconditional loads of two samples each.
 template <int C>
 __device__ __forceinline__ void issue_block(const float* __restrict__ audio, long n_samp,
                                             const long* __restrict__ pos, long fi, int hop, int lane,
                                             RawBlock<C>& raw) {
     const long p = pos[fi < 0 ? 0 : fi];
-    long nv = n_samp - p;
-    if (nv > hop) nv = hop;
-    if (nv > AUR_BLOCK) nv = AUR_BLOCK;
-    if (fi < 0) nv = 0;
-    raw.r = (int)nv - 2 * lane;
-    raw.shifted = 0;
-    const long last2 = n_samp - 2;
+    const unsigned long rem = (unsigned long)(n_samp - p);          // >= 1: pos is clamped to n_samp - 1
+    unsigned nv = (unsigned)(rem >> 32) != 0u ? (unsigned)AUR_BLOCK : (unsigned)rem;
+    nv = nv < (unsigned)AUR_BLOCK ? nv : (unsigned)AUR_BLOCK;
+    nv = nv < (unsigned)hop ? nv : (unsigned)hop;
+    if (fi < 0) nv = 0u;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(audio + p * C), 0, (int)(nv * (unsigned)(C * 4)), kRsrcWord3);
+    const int voff = lane * (2 * C * 4);
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
-        const long i0 = p + 2 * lane + 128 * jj;
-        const long ic = i0 < last2 ? i0 : last2;
-        if (i0 == last2 + 1) raw.shifted |= 1 << jj;
         if (C == 2) {
-            const f4a8 q = *reinterpret_cast<const f4a8*>(audio + ic * 2);   // (L0, R0, L1, R1)
-            raw.q[jj][0] = q.x;
-            raw.q[jj][1] = q.y;
-            raw.q[jj][2 * C - 2] = q.z;
-            raw.q[jj][2 * C - 1] = q.w;
+            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 128 * jj * C * 4, 0);   // (L0, R0, L1, R1)
+            raw.q[jj][0] = __uint_as_float(q.x);
+            raw.q[jj][1] = __uint_as_float(q.y);
+            raw.q[jj][2 * C - 2] = __uint_as_float(q.z);
+            raw.q[jj][2 * C - 1] = __uint_as_float(q.w);
         } else {
-            const f2a4 q = *reinterpret_cast<const f2a4*>(audio + ic);
-            raw.q[jj][0] = q.x;
-            raw.q[jj][2 * C - 1] = q.y;
+            const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 128 * jj * C * 4, 0);
+            raw.q[jj][0] = __uint_as_float(q.x);
+            raw.q[jj][2 * C - 1] = __uint_as_float(q.y);
         }
     }
 }
@@ -219,12 +213,9 @@ template <int C>
 __device__ __forceinline__ void mix_block(const RawBlock<C>& raw, float (&blk)[16]) {
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
-        // y.mean(axis=1) in float32: (L + R) rounded, then * 0.5 (exporter.py:234)
-        const float a = (C == 2) ? (raw.q[jj][0] + raw.q[jj][1]) * 0.5f : raw.q[jj][0];
-        const float b = (C == 2) ? (raw.q[jj][2 * C - 2] + raw.q[jj][2 * C - 1]) * 0.5f : raw.q[jj][2 * C - 1];
-        const float m0 = ((raw.shifted >> jj) & 1) ? b : a;
-        blk[2 * jj] = (128 * jj < raw.r) ? m0 : 0.0f;
-        blk[2 * jj + 1] = (128 * jj + 1 < raw.r) ? b : 0.0f;
+        // y.mean(axis=1) in float32: (L + R) rounded, then * 0.5 (exporter.py:234); padding zeros stay zero
+        blk[2 * jj] = (C == 2) ? (raw.q[jj][0] + raw.q[jj][1]) * 0.5f : raw.q[jj][0];
+        blk[2 * jj + 1] = (C == 2) ? (raw.q[jj][2 * C - 2] + raw.q[jj][2 * C - 1]) * 0.5f : raw.q[jj][2 * C - 1];
     }
 }
 
@@ -485,9 +476,12 @@ __device__ __forceinline__ v2f log1p_pos2(v2f x) {
 // W32^5 need a full product; T.wus equals T.wuh except in lane 0, where it carries the shift by 128 bins.
 // Returns this lane's flux partial.  When EMIT: lg0 / lg1 receive log1p|X| of bins lane and lane + 64 (band maxima),
 // and when STORE_LOG too, log1p|X| is stored to `out` (float32[1025]) as soon as it is known.
+// `out` is the frame's float32[1025] spectrum as a buffer resource (base = the frame's row, num_records = 4100 bytes): the
+// stores are buffer_store_dword with one lane-dependent offset register per direction and the bin steps as immediate
+// offsets -- no 64-bit address arithmetic per store.
 template <bool EMIT, bool STORE_LOG, typename PM, typename MID>
 __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, PM& pm,
-                                            float* __restrict__ out, float& lg0, float& lg1, MID&& mid_hook) {
+                                            const __amdgpu_buffer_rsrc_t out, float& lg0, float& lg1, MID&& mid_hook) {
     constexpr double H = 0.70710678118654752440;
     const bool l0 = lane == 0;
     const cd wuh = opaque(T.wuh);
@@ -502,11 +496,11 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
     th[6] = mul_mi(th[4]);                                             // j = 9
     th[7] = mul_mi(th[5]);                                             // j = 13
     v2f fl2 = {0.0f, 0.0f};
-    // per-frame store addresses; the 64 j steps are instruction offsets
-    float* const out_a = out + lane;
-    float* const out_b = out + (1024 - lane);
-    float* const out_a2 = out + T.off2;
-    float* const out_b2 = out + (1024 - T.off2);
+    // byte offsets of the stores: bin lane + 64 j = off_a + 256 j; bin 1024 - lane - 64 j = off_b + (3840 - 256 j) with
+    // off_b = 256 - 4 lane > 0; the shifted slots of lane 0 (bins off2 + 64 j and 1024 - off2 - 64 j, j = 8, 12) use
+    // off_a2 = 4 off2 and off_b2 = 4 (256 - off2) + 4 (768 - 64 j)
+    const int off_a = 4 * lane, off_b = 256 - 4 * lane;
+    const int off_a2 = 4 * T.off2, off_b2 = 4 * (256 - T.off2);
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         const int ql = p >> 2, s = p & 3, j = ql + 4 * s;
@@ -532,11 +526,11 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
             if (j == 1) lg1 = l.x;
             if (STORE_LOG) {
                 if (p == 2 || p == 3) {
-                    AUR_STFT_ST(out_a2 + 64 * j, l.x);         // bin off2 + 64 j
-                    AUR_STFT_ST(out_b2 - 64 * j, l.y);
+                    aur_buf_st(l.x, out, off_a2 + 256 * j);                 // bin off2 + 64 j
+                    aur_buf_st(l.y, out, off_b2 + 4 * (768 - 64 * j));      // bin 1024 - off2 - 64 j
                 } else {
-                    AUR_STFT_ST(out_a + 64 * j, l.x);          // bin lane + 64 j
-                    AUR_STFT_ST(out_b - 64 * j, l.y);          // bin 1024 - lane - 64 j
+                    aur_buf_st(l.x, out, off_a + 256 * j);                  // bin lane + 64 j
+                    aur_buf_st(l.y, out, off_b + (3840 - 256 * j));         // bin 1024 - lane - 64 j
                 }
             }
         }
@@ -547,7 +541,7 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
         const float mm = mag_from_sq(fma(z8.x, z8.x, z8.y * z8.y));
         if (l0) {
             fl += fmaxf(0.0f, mm - pm.swap_mid(mm));
-            if (EMIT && STORE_LOG) out[512] = log1p_pos(mm);
+            if (EMIT && STORE_LOG) aur_buf_st(log1p_pos(mm), out, 4 * 512);
         }
     }
     return fl;
@@ -623,6 +617,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     // requested after the FFT, before anything of this frame is stored, and is first touched at the end of the body:
     // gfx950 counts loads and stores in one in-order counter (vmcnt), so a load issued behind the 17 spectrum stores
     // of a frame could only be waited for by draining those stores first.
+    // (Alternating the roles of prv / cur over a loop unrolled by two instead of copying 16 registers per frame was
+    // measured: 27 VALU instructions fewer per frame, twice the code, 0.841 vs 0.828 ms -- not kept.)
     auto frame = [&](long f, auto store_tag) {
         constexpr bool STORE = decltype(store_tag)::value;
         const long fo = f - frame_begin;
@@ -630,17 +626,23 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
             const float ma = block_meanabs(cur, lane, xf);
             if (lane == 0) meanabs[fo] = ma;
             if (SAMPLES) {
-                float* dst = samples_out + fo * AUR_BLOCK;
+                const __amdgpu_buffer_rsrc_t srs =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(samples_out + fo * AUR_BLOCK), 0, AUR_BLOCK * 4, kRsrcWord3);
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj)
-                    *reinterpret_cast<float2*>(dst + 2 * lane + 128 * jj) = float2{cur[2 * jj], cur[2 * jj + 1]};
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(cur[2 * jj]), __float_as_uint(cur[2 * jj + 1])},
+                                                          srs, 8 * lane + 512 * jj, 0, 0);
             }
         }
         fft_packed(prv, cur, lane, T, xb, v);
         RawBlock<C> nxt;
         float lg0 = 0.0f, lg1 = 0.0f;
+        // the frame's spectrum row as a buffer resource (an empty one when nothing is stored: logspec may be NULL)
+        const bool row = STORE && LOG;
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(logspec + (row ? fo * AUR_NBINS : 0)), 0, row ? AUR_NBINS * 4 : 0, kRsrcWord3);
         float fl = unpack_mag<STORE && (LOG || BM), STORE && LOG>(
-            v, lane, T, pmag, logspec + fo * AUR_NBINS, lg0, lg1,
+            v, lane, T, pmag, ors, lg0, lg1,
             [&]() { issue_block<C>(audio, n_samp, pos, (f + 1 < cend) ? f + 1 : -1, hop, lane, nxt); });
         if (STORE) {
             fl = wave_sum(fl);
@@ -694,7 +696,8 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
     mags_load(pmag, prev_mag, lane);
     fft_packed(prv, cur, lane, T, xb, v);
     float lg0, lg1;
-    float fl = unpack_mag<true, true>(v, lane, T, pmag, logspec, lg0, lg1, []() {});
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)logspec, 0, AUR_NBINS * 4, kRsrcWord3);
+    float fl = unpack_mag<true, true>(v, lane, T, pmag, ors, lg0, lg1, []() {});
     mags_store(pmag, prev_mag, lane);
     fl = wave_sum(fl);
     if (lane == 0) flux_sum[0] = fl;

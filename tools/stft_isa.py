@@ -24,8 +24,12 @@ def main():
                                       text=True)
         vg = re.search(r"\.vgpr_count:\s+(\d+)", open(asm).read().split(KERNEL)[-1])
     m = re.search(r"total (\d+)\s+valu (\d+)\s+f64 (\d+)\s+lds (\d+)", txt)
-    out = {"kernel": KERNEL, "loop_instructions": int(m.group(1)), "valu_per_frame": int(m.group(2)),
-           "f64_per_frame": int(m.group(3)), "lds_per_frame": int(m.group(4)),
+    # the frame loop is unrolled by hand (ping-pong of the two block arrays): one frame = 64 ds_write_b64 of the exchanges
+    w = re.search(r"^\s*(\d+) ds_write_b64", txt, re.M)
+    frames = max(1, int(w.group(1)) // 64) if w else 1
+    out = {"kernel": KERNEL, "frames_per_loop_iteration": frames, "loop_instructions": int(m.group(1)),
+           "valu_per_frame": int(m.group(2)) // frames, "f64_per_frame": int(m.group(3)) // frames,
+           "lds_per_frame": int(m.group(4)) // frames,
            "vgprs": int(vg.group(1)) if vg else None, "histogram": txt.strip().split("\n")[1:]}
     path = os.path.join(ROOT, "profiles", "stft_isa.json")
     with open(path, "w") as fh:

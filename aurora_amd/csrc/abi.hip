@@ -90,6 +90,7 @@ extern "C" int aur_create(int device, aur_ctx** out) {
     build_tables(ctx->h_window, h_tw);
     hipError_t e = hipMalloc((void**)&ctx->d_window, sizeof(float) * AUR_FFT_SIZE);
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_twid, sizeof(h_tw));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_rows, (size_t)AUR_ROWS_BYTES + (size_t)AUR_ROWS_FLAGS * 4);
     if (e == hipSuccess)
         e = hipMemcpy(ctx->d_window, ctx->h_window, sizeof(float) * AUR_FFT_SIZE, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_twid, h_tw, sizeof(h_tw), hipMemcpyHostToDevice);
@@ -97,12 +98,14 @@ extern "C" int aur_create(int device, aur_ctx** out) {
         aur_set_error("aur_create: table upload failed: %s", hipGetErrorString(e));
         if (ctx->d_window) (void)hipFree(ctx->d_window);
         if (ctx->d_twid) (void)hipFree(ctx->d_twid);
+        if (ctx->d_rows) (void)hipFree(ctx->d_rows);
         free(ctx);
         return AUR_EHIP;
     }
     if (int rc = aur_raster_static_init(ctx)) {
         (void)hipFree(ctx->d_window);
         (void)hipFree(ctx->d_twid);
+        (void)hipFree(ctx->d_rows);
         free(ctx);
         return rc;
     }
@@ -115,6 +118,7 @@ extern "C" void aur_destroy(aur_ctx* ctx) {
     if (hipSetDevice(ctx->device) == hipSuccess) {
         if (ctx->d_window) (void)hipFree(ctx->d_window);
         if (ctx->d_twid) (void)hipFree(ctx->d_twid);
+        if (ctx->d_rows) (void)hipFree(ctx->d_rows);
     }
     free(ctx);
 }

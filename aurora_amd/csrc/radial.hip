@@ -663,6 +663,149 @@ __global__ __launch_bounds__(256) void raster_fill_planes_kernel(const uint32_t*
     }
 }
 
+// ---- two-pass plane fill (W % 32 == 0): linear background / disc fill, then patches where the stroke is ----------------
+//
+// The frames are written at the rate of the linear span fill (raster.hip: one 4 KB-aligned 4 KB piece per workgroup, one
+// non-temporal 16-byte store per lane) instead of the 16-row tiles above, whose per-tile mask loads come cold from HBM in
+// front of the stores (5.45 TB/s).  What a lane must know in pass 1 is small enough to stay in L2: the centre disc is one
+// pixel interval per row (disc_rows_kernel: first / last set bit of the row; a row whose bits are not contiguous is marked
+// and its disc pixels go through the patches too), 4 bytes per frame and row, one table for all frames when the disc is
+// static (the export default).  Pass 2 walks the stroke plane once, one lane per 32-pixel word, and rewrites the six
+// 16-byte columns (32 pixels = 96 bytes exactly) of the few words that have a bit set.
+constexpr uint32_t kRowMulti = 0xffffffffu;      // x0 = x1 = 65535: no pixel column of a frame lies inside, pass 1 paints background
+
+__global__ __launch_bounds__(256) void disc_rows_kernel(const uint32_t* __restrict__ disc, int H, int W32,
+                                                        uint32_t* __restrict__ rows) {
+    // one wave per row
+    const int f = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= H) return;
+    const uint32_t* src = disc + ((long)f * H + row) * W32;
+    int first = 1 << 30, last = -1, count = 0;
+    for (int w = lane; w < W32; w += 64) {
+        const uint32_t v = src[w];
+        if (v) {
+            const int lo = 32 * w + __builtin_ctz(v), hi = 32 * w + 31 - __builtin_clz(v);
+            first = lo < first ? lo : first;
+            last = hi > last ? hi : last;
+            count += __builtin_popcount(v);
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int of = __shfl_xor(first, m, 64), ol = __shfl_xor(last, m, 64);
+        first = of < first ? of : first;
+        last = ol > last ? ol : last;
+        count += __shfl_xor(count, m, 64);
+    }
+    if (lane == 0) {
+        uint32_t t = 0u;
+        if (count > 0) t = (count == last - first + 1) ? ((uint32_t)first | ((uint32_t)(last + 1) << 16)) : kRowMulti;
+        rows[(long)f * H + row] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void raster_fill_rows_kernel(const uint32_t* __restrict__ rows, int rows_static, int H,
+                                                               int nu4, int upf, float inv_upf, float inv_nu4, int head,
+                                                               unsigned total, uint4* __restrict__ frames) {
+    const unsigned gi = blockIdx.x * 256u + threadIdx.x;
+    if (gi < (unsigned)head) return;
+    const unsigned g = gi - (unsigned)head;
+    if (g >= total) return;
+    int f = (int)((float)g * inv_upf);
+    int u = (int)(g - (unsigned)f * (unsigned)upf);
+    if (u < 0) {
+        u += upf;
+        --f;
+    } else if (u >= upf) {
+        u -= upf;
+        ++f;
+    }
+    int row = (int)((float)u * inv_nu4);
+    int col = u - row * nu4;
+    if (col < 0) {
+        col += nu4;
+        --row;
+    } else if (col >= nu4) {
+        col -= nu4;
+        ++row;
+    }
+    const int fr = rows_static ? 0 : f;
+    const uint32_t t = rows[(long)fr * H + row];        // kRowMulti: this row's disc is painted by the patch pass
+    const int x0 = (int)(t & 0xffffu), x1 = (int)(t >> 16);
+    const int ph = col % 3, c0 = (16 * col) / 3;
+    constexpr uint32_t D0 = kBg24 | (kBg24 << 24), D1 = (kBg24 >> 8) | (kBg24 << 16), D2 = (kBg24 >> 16) | (kBg24 << 8);
+    uint4 o;
+    o.x = ph == 0 ? D0 : (ph == 1 ? D1 : D2);
+    o.y = ph == 0 ? D1 : (ph == 1 ? D2 : D0);
+    o.z = ph == 0 ? D2 : (ph == 1 ? D0 : D1);
+    o.w = o.x;
+    if (c0 < x1 && c0 + 6 > x0) {
+        uint32_t P[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) P[c] = (c0 + c >= x0 && c0 + c < x1) ? kDisc24 : kBg24;
+        o = pack_rgb16(P, ph);
+    }
+    aur_store_frame16(frames + g, o);
+}
+
+// Rewrites the six 16-byte columns of plane word i of frame f (32 pixels = 96 bytes) when a bit of it must be painted.
+__device__ __forceinline__ void patch_word(uint32_t sb, const uint32_t* __restrict__ disc_frame, bool disc_here, long i,
+                                           uint32_t pen, uint4* __restrict__ frame) {
+    uint32_t db = 0u;
+    if (disc_here || sb != 0u) db = disc_frame[i];                   // the disc is painted last: it covers the stroke
+    if (sb == 0u && !(disc_here && db != 0u)) return;
+    uint4* dst = frame + i * 6;
+    const uint32_t need = disc_here ? (sb | db) : sb;                 // pass 1 painted everything else of the word
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int c0 = (16 * k) / 3;                                  // 0, 5, 10, 16, 21, 26
+        if (((need >> c0) & 0x3fu) == 0u) continue;                   // this 16-byte column is already right
+        uint32_t P[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int b = c0 + c;                                     // <= 31
+            P[c] = ((db >> b) & 1u) ? kDisc24 : (((sb >> b) & 1u) ? pen : kBg24);
+        }
+        dst[k] = pack_rgb16(P, k % 3);
+    }
+}
+
+// VEC: one lane reads four stroke words with one 16-byte load (words % 4 == 0, 16-byte aligned plane); almost all of
+// them are zero, so the pass is a stream over the stroke plane.
+template <bool VEC>
+__global__ __launch_bounds__(256) void raster_patch_planes_kernel(const uint32_t* __restrict__ stroke,
+                                                                  const uint32_t* __restrict__ disc,
+                                                                  const uint32_t* __restrict__ rows,
+                                                                  const uint32_t* __restrict__ pen_rgb, int words,
+                                                                  int W32, int H, int disc_static,
+                                                                  uint4* __restrict__ frames) {
+    // words = H * W32 per frame; word i of frame f covers the uint4 columns 6 i .. 6 i + 5 of the frame (nu4 = 6 W32)
+    const int f = blockIdx.y;
+    const int fr = disc_static ? 0 : f;
+    const uint32_t* rf = rows + (long)fr * H;                         // kRowMulti: the row's disc is not in pass 1
+    const uint32_t* sf = stroke + (long)f * words;
+    const uint32_t* df = disc + (long)fr * words;
+    uint4* frame = frames + (long)f * words * 6;
+    const uint32_t pen = pen_rgb[f] & 0x00ffffffu;
+    if (VEC) {
+        const int i4 = blockIdx.x * 256 + threadIdx.x;
+        if (4 * i4 >= words) return;
+        const uint4 s4 = reinterpret_cast<const uint4*>(sf)[i4];
+        const bool disc_here = rf[(4 * i4) / W32] == kRowMulti;       // W32 % 4 == 0: the four words share a row
+        if (!disc_here && (s4.x | s4.y | s4.z | s4.w) == 0u) return;
+        patch_word(s4.x, df, disc_here, 4L * i4, pen, frame);
+        patch_word(s4.y, df, disc_here, 4L * i4 + 1, pen, frame);
+        patch_word(s4.z, df, disc_here, 4L * i4 + 2, pen, frame);
+        patch_word(s4.w, df, disc_here, 4L * i4 + 3, pen, frame);
+    } else {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= words) return;
+        patch_word(sf[i], df, rf[i / W32] == kRowMulti, i, pen, frame);
+    }
+}
+
 // plane &= ~(excl_a | excl_b), and the whole plane of a frame is cleared when enable[f] == 0.
 __global__ __launch_bounds__(256) void plane_exclude_kernel(uint32_t* __restrict__ plane,
                                                             const uint32_t* __restrict__ excl_a,
@@ -1200,6 +1343,32 @@ extern "C" int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, c
         return AUR_OK;
     }
     const int nu4 = W * 3 / 16, nchunks = (nu4 + 63) / 64;
+    const long upf_l = (long)nu4 * H;
+    const int table_frames = disc_static ? 1 : n_frames;
+    if (W % 32 == 0 && ctx->fill_mode != 1 && ctx->d_rows != nullptr && upf_l >= 256 && upf_l < (1L << 26) &&
+        (long)n_frames * upf_l + 256 < (1L << 31) &&
+        (size_t)table_frames * H * 4 <= (size_t)AUR_ROWS_BYTES) {
+        hipStream_t st = (hipStream_t)stream;
+        uint32_t* rows = reinterpret_cast<uint32_t*>(ctx->d_rows);
+        hipLaunchKernelGGL(disc_rows_kernel, dim3((H + 3) / 4, table_frames), dim3(256), 0, st, d_disc_plane, H, W32, rows);
+        const int upf = (int)upf_l;
+        const int head = (int)(((uintptr_t)d_frames & 4095u) / 16u);
+        const unsigned total = (unsigned)n_frames * (unsigned)upf;
+        const unsigned gfill = (unsigned)(((unsigned long)total + (unsigned)head + 255u) / 256u);
+        hipLaunchKernelGGL(raster_fill_rows_kernel, dim3(gfill), dim3(256), 0, st, rows, disc_static ? 1 : 0, H, nu4,
+                           upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, reinterpret_cast<uint4*>(d_frames));
+        const int words = H * W32;
+        if (W32 % 4 == 0 && ((uintptr_t)d_stroke_plane & 15u) == 0)
+            hipLaunchKernelGGL(raster_patch_planes_kernel<true>, dim3((words / 4 + 255) / 256, n_frames), dim3(256), 0, st,
+                               d_stroke_plane, d_disc_plane, rows, reinterpret_cast<const uint32_t*>(d_pen_rgb), words,
+                               W32, H, disc_static ? 1 : 0, reinterpret_cast<uint4*>(d_frames));
+        else
+            hipLaunchKernelGGL(raster_patch_planes_kernel<false>, dim3((words + 255) / 256, n_frames), dim3(256), 0, st,
+                               d_stroke_plane, d_disc_plane, rows, reinterpret_cast<const uint32_t*>(d_pen_rgb), words,
+                               W32, H, disc_static ? 1 : 0, reinterpret_cast<uint4*>(d_frames));
+        AUR_CHECK_HIP(hipGetLastError());
+        return AUR_OK;
+    }
     const int ntiles = (H + kRowsPerTask - 1) / kRowsPerTask;
     hipLaunchKernelGGL(raster_fill_planes_kernel, dim3((nchunks * ntiles + 3) / 4, n_frames), dim3(256), 0,
                        (hipStream_t)stream, d_stroke_plane, d_disc_plane, reinterpret_cast<const uint32_t*>(d_pen_rgb), W,

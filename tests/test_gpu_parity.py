@@ -1036,3 +1036,53 @@ def test_render_time_duck_type_equals_stream(eng, mode):
     fr = slow.render_time(70 / fps)
     assert fr.shape == (H, W, 3) and fr.tobytes() == buf.getvalue()[70 * W * H * 3:71 * W * H * 3]
     assert slow.render_time(3 / fps).tobytes() == buf.getvalue()[3 * W * H * 3:4 * W * H * 3]
+
+
+@pytest.mark.parametrize("size,offset16", [((640, 368), 0), ((1280, 720), 7), ((3840, 96), 0), ((96, 40), 3)])
+@pytest.mark.parametrize("disc_kind", ["static_contiguous", "static_holes", "per_frame_mixed"])
+def test_raster_planes_two_pass_equals_definition(eng, size, offset16, disc_kind):
+    """aur_raster_planes (W % 32 == 0: linear background / disc-interval fill + stroke patches) on synthetic planes against
+    the definition: background, stroke bits in the pen colour, disc bits on top in (30, 30, 40).  Disc rows with one pixel
+    interval go through the row table; frames with a row of several intervals are flagged and painted by the patch pass;
+    a frame base that is not 4 KB aligned; nothing written outside the batch."""
+    import torch
+    W, H = size
+    F, W32 = 4, W // 32
+    rng = np.random.default_rng(W + 7 * offset16 + len(disc_kind))
+    stroke = np.zeros((F, H, W), bool)
+    for f in range(F):
+        for _ in range(40):
+            r, c = int(rng.integers(0, H)), int(rng.integers(0, W))
+            stroke[f, r:r + int(rng.integers(1, 4)), c:c + int(rng.integers(1, 40))] = True
+        stroke[f, 0, 0] = stroke[f, H - 1, W - 1] = True
+    nd = 1 if disc_kind.startswith("static") else F
+    disc = np.zeros((nd, H, W), bool)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for f in range(nd):
+        cx, cy, rad = W / 2 + 3 * f, H / 2, 0.3 * min(W, H)
+        disc[f] = (xx - cx) ** 2 + (yy - cy) ** 2 <= rad * rad
+        if disc_kind == "static_holes" or (disc_kind == "per_frame_mixed" and f % 2 == 1):
+            disc[f, :, int(cx) - 2:int(cx) + 3] = False                  # every disc row splits into two intervals
+        if disc_kind == "per_frame_mixed" and f == 2:
+            disc[f] = False                                              # an empty disc plane
+
+    def pack(b):
+        return np.packbits(b.reshape(b.shape[0], H, W32, 32), axis=-1, bitorder="little").view(np.uint32)[..., 0]
+
+    pen = rng.integers(0, 256, size=(F, 4), dtype=np.uint8)
+    pen[:, 3] = 0
+    d_stroke = torch.from_numpy(pack(stroke).view(np.int32)).to(eng.device)
+    d_disc = torch.from_numpy(pack(disc).view(np.int32)).to(eng.device)
+    d_pen = torch.from_numpy(pen).to(eng.device)
+    raw = torch.full((F * H * W * 3 + 16 * offset16 + 4096,), 0x5A, dtype=torch.uint8, device=eng.device)
+    out = raw[16 * offset16:16 * offset16 + F * H * W * 3].view(F, H, W, 3)
+    eng.fill_planes((d_stroke, d_disc, nd == 1), d_pen, W, H, out=out)
+    got = _np(out)
+    want = np.empty((F, H, W, 3), np.uint8)
+    want[:] = np.asarray(R.BG, np.uint8)
+    for f in range(F):
+        want[f][stroke[f]] = pen[f, :3]
+        want[f][disc[0 if nd == 1 else f]] = np.asarray(R.DISC_RGB, np.uint8)
+    assert np.array_equal(got, want), int(np.sum(got != want))
+    r = _np(raw)
+    assert (r[:16 * offset16] == 0x5A).all() and (r[16 * offset16 + F * H * W * 3:] == 0x5A).all()

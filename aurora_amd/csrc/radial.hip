@@ -467,36 +467,41 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
     }
 }
 
-// Even-odd fill of the implicitly closed polygon verts[f][nv][2].  The edges append their
-// crossings to the lists of the few pixel rows they span, a thread per row sorts its list into pixel spans in LDS;
-// then the block writes its rows word by word as one contiguous piece of the plane.  Every word of the plane is written,
-// so the plane needs no clearing.
+// Even-odd fill of the implicitly closed polygon verts[f][nv][2], sampled at pixel centres.  A pixel is inside iff an odd
+// number of edge crossings of its row lie at or left of it, so every crossing simply TOGGLES one bit of the row -- the
+// first pixel at or right of it -- in an LDS bitmap (atomicXor: order-free, any number of crossings per row, nothing to
+// sort or to overflow), and the fill is the prefix XOR of that bitmap along the row.  Rows with an odd number of
+// crossings (only NaN vertices produce them) drop their right-most crossing, as the sorted-pair rule of the oracle does.
+// The block then writes its rows as one contiguous piece of the plane; every word is written, so the plane needs no
+// clearing.
 __device__ __forceinline__ int span_edge(double x, int W) {
     const double a = fmin(fmax(x, -kBig), kBig);
     const int c = (int)ceil(a - 0.5);
     return c < 0 ? 0 : (c > W ? W : c);
 }
-// ROWS pixel rows per block of 128 threads, CROSS crossings kept per row: <128, 32> for the 361-vertex envelopes
-// (a star-shaped envelope has 2 crossings per row, wavy ones a few), <32, 256> for the fill polygon of the radial /
-// circular path, whose spikes can cross a row near the top or bottom tangent dozens of times.
-template <int ROWS, int CROSS>
+constexpr int kPolyWords = 8192;     // LDS bitmap of a block: rows_per_block * W32 <= this (32 KB)
 __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restrict__ verts, int nv, int W, int H,
-                                                           int W32, int vec_ok, uint32_t* __restrict__ planes) {
-    // sorted crossings of each row (+1: rows on different banks); once sorted they are converted in place to clipped
-    // pixel-span edges (int i overlays the first half of double i / 2, which has been read by then)
-    __shared__ double s_xs[ROWS][CROSS + 1];
-    __shared__ int s_cnt[ROWS];
+                                                           int W32, int rows_per_block, int vec_ok,
+                                                           uint32_t* __restrict__ planes) {
+    __shared__ uint32_t s_bits[kPolyWords];      // [row][word]: toggles, then the filled words
+    __shared__ uint8_t s_par[kPolyWords];        // parity of the toggles of a word, then the carry into it
+    __shared__ int s_cnt[128], s_max[128];       // crossings of a row and the right-most toggle position
     const int f = blockIdx.y;
     const double* V = verts + (long)f * nv * 2;      // edges read their end points from global memory (L2-resident)
+    const int base = blockIdx.x * rows_per_block;
+    const int rows_here = (H - base < rows_per_block) ? H - base : rows_per_block;
+    const int total = rows_here * W32;
+    for (int idx = threadIdx.x; idx < total; idx += 128) s_bits[idx] = 0u;
+    if (threadIdx.x < rows_per_block) {
+        s_cnt[threadIdx.x] = 0;
+        s_max[threadIdx.x] = -1;
+    }
+    int found = 0;
+    __syncthreads();
     // Edge-parallel crossing search: an edge crosses the sample line of row r (y = r + 0.5) iff exactly one of its end
     // points is <= it, i.e. for the rows between ceil(ymin - 0.5) and ceil(ymax - 0.5) - 1; a thread walks the few rows
     // of its edges (one candidate row more on either side, every row decided by the exact predicate, so rounding of
-    // the bounds cannot change the result) and appends the crossing to the row's list.  Rows are sorted afterwards, so
-    // the append order does not matter (lists longer than CROSS keep an unspecified subset).
-    const int base = blockIdx.x * ROWS;
-    if (threadIdx.x < ROWS) s_cnt[threadIdx.x] = 0;
-    int found = 0;
-    __syncthreads();
+    // the bounds cannot change the result).
     for (int e = threadIdx.x; e < nv; e += 128) {
         const int ep = (e == 0) ? nv - 1 : e - 1;
         const double x0 = V[2 * ep], y0 = V[2 * ep + 1], x1 = V[2 * e], y1 = V[2 * e + 1];
@@ -506,20 +511,20 @@ __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restr
         yb = fmin(fmax(yb, -kBig), kBig);
         long ra = (long)ceil(ya - 0.5) - 1, rb = (long)ceil(yb - 0.5);
         if (ra < base) ra = base;
-        if (rb > base + ROWS - 1) rb = base + ROWS - 1;
-        if (rb > H - 1) rb = H - 1;
+        if (rb > base + rows_here - 1) rb = base + rows_here - 1;
         for (long r = ra; r <= rb; ++r) {
             const double yc = (double)r + 0.5;
             if ((y0 <= yc) != (y1 <= yc)) {
                 const double x = x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0);
-                const int slot = atomicAdd(&s_cnt[r - base], 1);
-                if (slot < CROSS) s_xs[r - base][slot] = x;
+                const int c = span_edge(x, W);                       // first pixel whose centre is at or right of x
+                const int rr = (int)(r - base);
+                atomicAdd(&s_cnt[rr], 1);
+                atomicMax(&s_max[rr], c);
+                if (c < W) atomicXor(&s_bits[rr * W32 + (c >> 5)], 1u << (c & 31));
                 found = 1;
             }
         }
     }
-    const int rows_here = (H - base < ROWS) ? H - base : ROWS;
-    const int total = rows_here * W32;
     uint32_t* dst = planes + ((long)f * H + base) * W32;
     if (__syncthreads_or(found) == 0) {                               // no edge crosses these rows: zeros
         if (vec_ok) {                                                 // W32 % 4 == 0 and a 16-byte aligned plane
@@ -530,44 +535,40 @@ __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restr
         }
         return;
     }
-    if (threadIdx.x < ROWS) {
-        int m = s_cnt[threadIdx.x];
-        if (m > CROSS) m = CROSS;
-        double* xs = s_xs[threadIdx.x];
-        for (int i = 1; i < m; ++i) {                                 // insertion sort of the row's crossings
-            const double x = xs[i];
-            int k = i;
-            while (k > 0 && xs[k - 1] > x) {
-                xs[k] = xs[k - 1];
-                --k;
-            }
-            xs[k] = x;
-        }
-        m &= ~1;
-        int* cs = reinterpret_cast<int*>(xs);
-        for (int i = 0; i < m; ++i) {
-            const int c = span_edge(xs[i], W);
-            cs[i] = c;
-        }
-        s_cnt[threadIdx.x] = m;
+    if (threadIdx.x < rows_here && (s_cnt[threadIdx.x] & 1)) {        // odd count: the right-most crossing is dropped
+        const int c = s_max[threadIdx.x];
+        if (c >= 0 && c < W) s_bits[threadIdx.x * W32 + (c >> 5)] ^= 1u << (c & 31);
     }
     __syncthreads();
-    // the block's rows are one contiguous piece of the plane: the threads write it word by word (128 consecutive words
-    // per step, independent steps, so the LDS reads of several steps overlap)
+    // prefix XOR inside every word, parity of every word
+    for (int idx = threadIdx.x; idx < total; idx += 128) {
+        uint32_t t = s_bits[idx];
+        s_par[idx] = (uint8_t)(__builtin_popcount(t) & 1);
+        t ^= t << 1;
+        t ^= t << 2;
+        t ^= t << 4;
+        t ^= t << 8;
+        t ^= t << 16;
+        s_bits[idx] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < rows_here) {                                    // carry along the row: inside / outside at each word start
+        uint8_t* par = s_par + threadIdx.x * W32;
+        uint8_t carry = 0;
+        for (int w = 0; w < W32; ++w) {
+            const uint8_t p = par[w];
+            par[w] = carry;
+            carry ^= p;
+        }
+    }
+    __syncthreads();
+    const uint32_t tail = (W & 31) ? ((1u << (W & 31)) - 1u) : 0xffffffffu;   // bits past the last pixel stay 0
     const uint32_t inv = 0xffffffffu / (uint32_t)W32 + 1u;            // idx / W32 == (idx * inv) >> 32 for idx < 2^16
-#pragma unroll 4
     for (int idx = threadIdx.x; idx < total; idx += 128) {
         const int rr = (int)__umulhi((uint32_t)idx, inv);
         const int w = idx - rr * W32;
-        const int cnt = s_cnt[rr];
-        const int* cs = reinterpret_cast<const int*>(s_xs[rr]);
-        uint32_t bits = 0;
-        for (int i = 0; i < cnt; i += 2) {                // pixel centre px + 0.5 in [x_i, x_i+1)
-            const int c0 = cs[i], c1 = cs[i + 1];
-            const int a = c0 > 32 * w ? c0 : 32 * w;
-            const int b = c1 < 32 * w + 32 ? c1 : 32 * w + 32;
-            if (b > a) bits |= (0xffffffffu >> (32 - (b - a))) << (a - 32 * w);
-        }
+        uint32_t bits = s_bits[idx] ^ (s_par[idx] ? 0xffffffffu : 0u);
+        if (w == W32 - 1) bits &= tail;
         dst[idx] = bits;
     }
 }
@@ -1298,13 +1299,14 @@ extern "C" int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_verti
     AUR_REQUIRE(d_verts && d_plane, "aur_mask_polygon: null device pointer");
     const int W32 = (W + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
+    // rows per block: as many as fit the block's LDS bitmap, at most one per thread; a multiple of 4 keeps the uint4
+    // zero fill of empty blocks aligned
+    int rpb = kPolyWords / W32;
+    rpb = rpb > 128 ? 128 : rpb;
+    rpb &= ~3;
     const int vec_ok = (W32 % 4 == 0 && ((uintptr_t)d_plane & 15u) == 0) ? 1 : 0;   // rows of empty blocks as uint4
-    if (n_vertices <= 384)      // envelopes and feather rings
-        hipLaunchKernelGGL((mask_polygon_kernel<128, 32>), dim3((H + 127) / 128, n_frames), dim3(128), 0, st, d_verts,
-                           n_vertices, W, H, W32, vec_ok, d_plane);
-    else                        // fill polygon of the radial / circular path
-        hipLaunchKernelGGL((mask_polygon_kernel<32, 256>), dim3((H + 31) / 32, n_frames), dim3(128), 0, st, d_verts,
-                           n_vertices, W, H, W32, vec_ok, d_plane);
+    hipLaunchKernelGGL(mask_polygon_kernel, dim3((H + rpb - 1) / rpb, n_frames), dim3(128), 0, st, d_verts, n_vertices, W,
+                       H, W32, rpb, vec_ok, d_plane);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -266,8 +266,8 @@ int aur_wave_circular_vertices(aur_ctx* ctx, const float* d_samples, const doubl
  *   (`p.drawPath(path)` with the width-2 pen, rt_widget.py:975-981);
  * aur_mask_polygon: even-odd fill of the implicitly closed polygon, sampled at pixel centres
  *   (`p.fillPath(path, QColor(30,30,40))` under the clip, rt_widget.py:1056-1096; edge antialiasing not reproduced);
- *   up to 32 crossings per pixel row are kept for polygons of at most 384 vertices (envelopes, feather rings), up to
- *   256 for longer ones (the fill polygon of the radial / circular path, rt_widget.py:856-864).
+ *   any number of edge crossings per pixel row (every crossing toggles one bit of the row, the fill is the prefix XOR:
+ *   deterministic whatever the polygon, e.g. the noisy fill polygon of the circular waveform, rt_widget.py:856-864).
  * Both overwrite the whole plane. */
 int aur_mask_stroke_closed(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
                            uint32_t* d_plane, void* stream);

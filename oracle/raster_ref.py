@@ -442,8 +442,7 @@ def polygon_mask(verts, w, h, max_cross=None):
             x1, y1 = V[(e + 1) % n]
             if (y0 <= yc) != (y1 <= yc):
                 xs.append(x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0))
-        xs.sort()       # the kernel keeps at most 32 crossings per row; envelopes and smoothed rings stay below that
-        assert len(xs) <= (max_cross or (32 if n <= 384 else 256))
+        xs.sort()       # any number of crossings per row (an odd count, which only NaN vertices produce, drops the last)
         for i in range(0, len(xs) - 1, 2):
             a = min(max(xs[i], -_BIG), _BIG)
             b = min(max(xs[i + 1], -_BIG), _BIG)

@@ -1086,3 +1086,37 @@ def test_raster_planes_two_pass_equals_definition(eng, size, offset16, disc_kind
     assert np.array_equal(got, want), int(np.sum(got != want))
     r = _np(raw)
     assert (r[:16 * offset16] == 0x5A).all() and (r[16 * offset16 + F * H * W * 3:] == 0x5A).all()
+
+
+@pytest.mark.parametrize("size", [(640, 64), (3840, 40), (1000, 33)])
+def test_polygon_fill_with_hundreds_of_crossings_per_row(eng, size):
+    """Worst case of `_apply_fill` (rt_widget.py:856-864): the fill polygon of a full-scale white-noise circular waveform
+    (1024 vertices) and a 3951-vertex mirrored radial ring at a small height, where the top and bottom tangent rows are
+    crossed hundreds of times.  The even-odd fill must equal the oracle's sorted-pair rule exactly (no crossing limit,
+    no dependence on atomic order: two launches give the same plane)."""
+    import ctypes as C
+    import torch
+    W, H = size
+    rng = np.random.default_rng(W)
+    polys = []
+    for n in (1024, 3951):
+        a = 2.0 * np.pi * np.arange(n) / n
+        r = 0.45 * H * (0.55 + 0.45 * rng.uniform(-1.0, 1.0, n))          # spikes between 0.05 and 0.45 H
+        polys.append(np.stack([W / 2 + np.cos(a) * r * (W / H) * 0.9, H / 2 + np.sin(a) * r], axis=1))
+    for verts in polys:
+        n = verts.shape[0]
+        d_v = torch.from_numpy(np.ascontiguousarray(verts[None])).to(eng.device)
+        W32 = (W + 31) // 32
+        planes = []
+        for _ in range(2):
+            plane = torch.full((1, H, W32), -1, dtype=torch.int32, device=eng.device)
+            rc = eng.lib.aur_mask_polygon(eng.ctx.handle, C.c_void_p(d_v.data_ptr()), n, 1, W, H,
+                                          C.c_void_p(plane.data_ptr()), eng.stream())
+            assert rc == 0, eng.lib.aur_last_error()
+            planes.append(_np(plane)[0].view(np.uint32))
+        want = R.polygon_mask(verts, W, H)
+        below = verts[:, 1][None, :] <= (np.arange(H) + 0.5)[:, None]
+        ncross = int((below != np.roll(below, -1, axis=1)).sum(axis=1).max())
+        assert ncross > (32 if n <= 384 else 150) and (n < 3000 or ncross > 256)   # beyond the former per-row limits
+        assert np.array_equal(planes[0], planes[1])
+        assert np.array_equal(planes[0], want), int(np.count_nonzero(planes[0] != want))

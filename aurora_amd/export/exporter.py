@@ -363,6 +363,24 @@ class _PipeSink:
         self._stdin.write(buf)
 
 
+def _grow_pipe(stream, want=1 << 20):
+    """A 4K rgb24 frame is 24.9 MB and Linux pipes default to 64 KB, i.e. ~380 writer/reader hand-overs per frame:
+    ask for the largest pipe an unprivileged process may have (/proc/sys/fs/pipe-max-size, 1 MiB by default).  Best
+    effort: any failure leaves the default pipe in place."""
+    try:
+        import fcntl
+        limit = want
+        try:
+            with open("/proc/sys/fs/pipe-max-size") as fh:
+                limit = min(want, int(fh.read().strip()))
+        except (OSError, ValueError):
+            pass
+        fcntl.fcntl(stream.fileno(), getattr(fcntl, "F_SETPIPE_SZ", 1031), limit)
+        return limit
+    except Exception:
+        return 0
+
+
 class _TailReader:
     """Reads a child's pipe to its end on a daemon thread, keeping the last ``keep`` bytes."""
 
@@ -471,6 +489,7 @@ class Exporter:
         # FFmpeg prints statistics while it encodes: both pipes are drained while the frames are written, or the child
         # blocks on a full pipe a few minutes in and the writer behind it for good.  The tail of stderr is kept for the
         # error message.
+        _grow_pipe(proc.stdin)
         tail = _TailReader(proc.stderr, keep=1 << 16)
         sinkhole = _TailReader(proc.stdout, keep=0)
         try:

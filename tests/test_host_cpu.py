@@ -576,3 +576,20 @@ def test_numpy_cabs_formula():
     fma = (d.astype(np.float64) * d.astype(np.float64) + 1.0).astype(f32)     # exact product, one rounding
     want = (mx * np.sqrt(fma)).astype(f32)
     assert np.array_equal(np.abs(z), want)
+
+
+def test_ffmpeg_pipe_is_grown():
+    """`_run_pipe` asks for a 1 MiB pipe (a 4K frame is 24.9 MB; the default pipe holds 64 KB)."""
+    import fcntl
+    import subprocess
+    import sys
+    from aurora_amd.export.exporter import _grow_pipe
+    proc = subprocess.Popen([sys.executable, "-c", "import sys; sys.stdin.buffer.read()"], stdin=subprocess.PIPE)
+    try:
+        got = _grow_pipe(proc.stdin)
+        size = fcntl.fcntl(proc.stdin.fileno(), getattr(fcntl, "F_GETPIPE_SZ", 1032))
+        assert got == 0 or size >= got >= 65536
+    finally:
+        proc.stdin.close()
+        proc.wait()
+    assert _grow_pipe(object()) == 0                 # anything that is not a pipe: left alone

@@ -4,7 +4,8 @@
 set -e
 tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-BENCH="bench.py --steps 1 --warmup 0 --cpu-frames 0 --pcie-frames 0"
+# a short export leg (4 s of audio) + one warm-up and one timed device-side step over the 1 h unit
+BENCH="bench.py --seconds 4 --steps 1 --warmup 0 --cpu-frames 0 --yuv-leg 0 --device-steps 1"
 out=gpurun_out/pmc_$tag
 mkdir -p $out
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o p -- python3 $BENCH > $out/fetch.log 2>&1

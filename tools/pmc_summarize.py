@@ -23,16 +23,25 @@ def short(name):
 
 
 def main(root):
-    agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    # a kernel may be launched in several shapes in one bench run (the short export leg, the 1 h device leg): only the
+    # dispatches with the kernel's LARGEST grid are aggregated (216 000-frame STFT launches, full 64-frame fill batches)
+    rows = []
     for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as fh:
             for row in csv.DictReader(fh):
                 k = short(row["Kernel_Name"])
-                if k is None:
-                    continue
-                a = agg[k][row["Counter_Name"]]
-                a[0] += float(row["Counter_Value"])
-                a[1] += 1
+                if k is not None:
+                    rows.append((k, int(float(row.get("Grid_Size", 0) or 0)), row["Counter_Name"],
+                                 float(row["Counter_Value"])))
+    biggest = defaultdict(int)
+    for k, grid, _, _ in rows:
+        biggest[k] = max(biggest[k], grid)
+    agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for k, grid, name, value in rows:
+        if grid == biggest[k]:
+            a = agg[k][name]
+            a[0] += value
+            a[1] += 1
     out = {}
     for k, counters in sorted(agg.items()):
         out[k] = {c: {"mean_per_dispatch": v[0] / v[1], "dispatches": v[1]} for c, v in sorted(counters.items())}
@@ -45,9 +54,9 @@ def main(root):
         if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             return None
         return int(round(2 * 1024 * c["FETCH_SIZE"]["mean_per_dispatch"] + 1024 * c["WRITE_SIZE"]["mean_per_dispatch"]))
-    tj = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py --steps 1 --warmup 0 "
-                    "--cpu-frames 0 --pcie-frames 0` (tools/pmc_passes.sh); bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE",
-          "raster_fill": {"config": os.environ.get("AUR_PMC_FILL_CONFIG", "3840x2160x128"),
+    tj = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py "
+                    "--seconds 4 --steps 1 --warmup 0 --cpu-frames 0 --yuv-leg 0 --device-steps 1` (tools/pmc_passes.sh; largest-grid dispatches of each kernel); bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE",
+          "raster_fill": {"config": os.environ.get("AUR_PMC_FILL_CONFIG", "3840x2160x64"),
                           "kernel": "raster_fill_lin_kernel",
                           "hbm_bytes_per_launch": traffic("raster_fill_lin_kernel")},
           "stft": {"frames": int(os.environ.get("AUR_PMC_STFT_FRAMES", "216000")),

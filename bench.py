@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--wire", default="rgb24", choices=("rgb24", "yuv420p"), help="wire format of the headline leg")
     ap.add_argument("--device-seconds", type=float, default=3600.0, help="track of the device-side leg (configs[4] unit)")
     ap.add_argument("--device-steps", type=int, default=2, help="timed steps of the device-side leg (0 = skip)")
+    ap.add_argument("--device-warmup", type=int, default=1, help="untimed steps of the device-side leg")
     ap.add_argument("--cpu-frames", type=int, default=240, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-cores CPU figure (0 = box share)")
     ap.add_argument("--yuv-leg", type=int, default=1, help="also time one export step in the opt-in yuv420p wire format")
@@ -195,26 +196,30 @@ def main():
         assert n == F and sink.bytes == F * pipe.frame_bytes
         return n
 
-    pipe = make_pipe(args.wire)                    # device slots + pinned ring allocated here, before the clock
-    for _ in range(args.warmup):
-        export_step(pipe)
-    ev_fill, ev_stft_small = [], []
-    if not planes_mode:
-        pipe.fill_events = ev_fill
-    pipe.stft_events = ev_stft_small
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        export_step(pipe)
-    barrier()
-    dt = time.perf_counter() - t0
-    dt = sharding.max_over_ranks(dt, device if backend == "nccl" else None)
-    roof = kernel_stats(ev_fill, frame_bytes)
-    wire_bytes = pipe.frame_bytes
-    pipe.fill_events = pipe.stft_events = None
-    pipe.close()
-    del pipe
-    value = world * F * args.steps / dt
+    if args.steps <= 0:                            # counter passes profile the device leg alone: no export leg
+        args.warmup, args.yuv_leg = 0, 0
+    roof, wire_bytes, dt = None, frame_bytes, 1.0
+    if args.steps > 0:
+        pipe = make_pipe(args.wire)                    # device slots + pinned ring allocated here, before the clock
+        for _ in range(args.warmup):
+            export_step(pipe)
+        ev_fill, ev_stft_small = [], []
+        if not planes_mode:
+            pipe.fill_events = ev_fill
+        pipe.stft_events = ev_stft_small
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            export_step(pipe)
+        barrier()
+        dt = time.perf_counter() - t0
+        dt = sharding.max_over_ranks(dt, device if backend == "nccl" else None)
+        roof = kernel_stats(ev_fill, frame_bytes)
+        wire_bytes = pipe.frame_bytes
+        pipe.fill_events = pipe.stft_events = None
+        pipe.close()
+        del pipe
+    value = world * F * args.steps / dt if args.steps > 0 else None
     link_gbs = F * args.steps / dt * wire_bytes / 1e9                 # per GPU (the slowest rank's)
 
     yuv_fps = None
@@ -292,7 +297,8 @@ def main():
                 done += n
                 i += 1
 
-        step()
+        for _ in range(args.device_warmup):
+            step()
         ev_f, ev_s = [], []
         barrier()
         t1 = time.perf_counter()
@@ -342,9 +348,11 @@ def main():
     try:                                               # per-launch HBM bytes from separate --pmc passes, if collected
         with open(args.traffic_json) as fh:
             tj = json.load(fh)
-        key = f"{W}x{H}x{B}"
-        if roof is not None and not planes_mode and tj.get("raster_fill", {}).get("config") == key:
-            roof["traffic"] = tj["raster_fill"]["hbm_bytes_per_launch"]
+        rf = tj.get("raster_fill", {})
+        if roof is not None and not planes_mode and rf.get("config") == f"{W}x{H}" and rf.get("hbm_bytes_per_launch"):
+            # collected on 128-frame launches (rocprofv3's counter mode does not survive more dispatches per process
+            # here); the fill's traffic is linear in the frames of a launch
+            roof["traffic"] = int(round(rf["hbm_bytes_per_launch"] * roof["frames_per_launch"] / rf["frames_per_launch"]))
         if roof_stft is not None and tj.get("stft", {}).get("frames") == roof_stft["frames_per_launch"]:
             roof_stft["traffic"] = tj["stft"]["hbm_bytes_per_launch"]
     except (OSError, ValueError):
@@ -357,8 +365,8 @@ def main():
     if rank == 0:
         out = {
             "metric": "exported frames/sec (whole node) 4K60 spectrum mode at 1/2/4/8 GPUs; STFT GB/s",
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "value": round(value, 1) if value is not None else None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 FFT / f32 magnitudes / u8 RGB24",
             "data": "synthetic",
             "config": {"workload": f"{args.seconds:.0f} s {sr} Hz stereo pink-noise track per GPU (resident in HBM), "

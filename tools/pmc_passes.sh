@@ -4,8 +4,9 @@
 set -e
 tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-# a short export leg (4 s of audio) + one warm-up and one timed device-side step over the 1 h unit
-BENCH="bench.py --seconds 4 --steps 1 --warmup 0 --cpu-frames 0 --yuv-leg 0 --device-steps 1"
+# the device-side leg alone (no export leg: counter collection serialises the queues, the readback pipeline is left
+# out): one warm-up and one timed step over the 1 h unit
+BENCH="bench.py --seconds 4 --steps 0 --cpu-frames 0 --device-steps 1 --device-warmup 0 --batch 128"
 out=gpurun_out/pmc_$tag
 mkdir -p $out
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o p -- python3 $BENCH > $out/fetch.log 2>&1

@@ -5,12 +5,15 @@ tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err || exit 1
+if [ "$2" != "nobench" ]; then timeout -k 10 400 python3 bench.py > $out/bench.json 2> $out/bench.err || exit 1; fi
 echo "bench done"
-timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $out/prof -o bench -- \
-    python3 bench.py --cpu-frames 0 > $out/prof_bench.json 2> $out/prof.err || exit 1
+# the kernels at speed: the device-side leg alone (per-kernel averages that the bench line's HIP-event figures must match)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_device -o bench -- \
+    python3 bench.py --seconds 4 --steps 0 --cpu-frames 0 > $out/prof_device_bench.json 2> $out/prof_device.err || exit 1
+rm -f $out/prof_device/bench_kernel_trace.csv
+# the export leg: kernels, blit copies (the device-to-host readback runs as __amd_rocclr_copyBuffer) and memory copies
+timeout -k 10 400 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $out/prof_export -o bench -- \
+    python3 bench.py --seconds 60 --steps 1 --warmup 1 --cpu-frames 0 --device-steps 0 > $out/prof_export_bench.json 2> $out/prof_export.err || exit 1
+rm -f $out/prof_export/bench_kernel_trace.csv $out/prof_export/bench_memory_copy_trace.csv
 echo "profile done"
-# the per-call traces are large: keep the statistics and the first 4000 lines of the copy trace
-head -4000 $out/prof/bench_memory_copy_trace.csv > $out/prof/bench_memory_copy_trace_head.csv 2>/dev/null
-rm -f $out/prof/bench_kernel_trace.csv $out/prof/bench_memory_copy_trace.csv
 bash tools/pmc_passes.sh $tag || exit 1

@@ -25,6 +25,7 @@ SYMBOLS = (
     "aur_radial_stage1", "aur_radial_ema", "aur_radial_vertices", "aur_envelope_vertices",
     "aur_feather_ring_vertices", "aur_blend_planes", "aur_add_planes", "aur_plane_exclude", "aur_wave_circular_vertices", "aur_mask_stroke_closed", "aur_mask_stroke_path", "aur_wave_linear_vertices", "aur_mask_polygon", "aur_raster_planes",
     "aur_rgb24_to_yuv420p",
+    "aur_image_scale", "aur_center_image_placement", "aur_disc_composite", "aur_blend_pixels", "aur_compose_background", "aur_set_background",
     "aur_host_alloc", "aur_host_free", "aur_readback_async", "aur_stream_synchronize",
 )
 
@@ -82,6 +83,19 @@ class EnvelopeParams(C.Structure):
     ]
 
 
+class DiscSource(C.Structure):
+    """struct aur_disc_source (include/aurora_hip.h)."""
+    _fields_ = [
+        ("mode", C.c_int32),
+        ("colour_argb_pm", C.c_uint32),
+        ("d_image", C.c_void_p),
+        ("img_w", C.c_int32),
+        ("img_h", C.c_int32),
+        ("d_placement", C.c_void_p),
+        ("placement_static", C.c_int32),
+    ]
+
+
 _lock = threading.Lock()
 _lib = None
 
@@ -126,6 +140,13 @@ def _declare(lib):
     lib.aur_wave_linear_vertices.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.aur_mask_polygon.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.aur_raster_planes.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp]
+    lib.aur_image_scale.argtypes = [vp, vp, i32, i32, vp, i32, i32, vp]
+    lib.aur_center_image_placement.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.aur_disc_composite.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(DiscSource), i32,
+                                       vp, vp, vp]
+    lib.aur_blend_pixels.argtypes = [vp, vp, vp, i32, C.c_uint32, i32, i32, i32, vp, vp]
+    lib.aur_compose_background.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.aur_set_background.argtypes = [vp, vp, i32, i32]
     lib.aur_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     lib.aur_host_free.argtypes = [vp]
     lib.aur_readback_async.argtypes = [vp, vp, C.c_size_t, vp, vp]

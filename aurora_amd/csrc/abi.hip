@@ -123,6 +123,27 @@ extern "C" void aur_destroy(aur_ctx* ctx) {
     free(ctx);
 }
 
+extern "C" int aur_set_background(aur_ctx* ctx, const uint8_t* d_base, int W, int H) {
+    AUR_REQUIRE(ctx != nullptr, "aur_set_background: null context");
+    if (d_base == nullptr) {
+        ctx->d_base = nullptr;
+        ctx->base_w = ctx->base_h = 0;
+        return AUR_OK;
+    }
+    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_set_background: frame size %dx%d unsupported", W, H);
+    AUR_REQUIRE(((uintptr_t)d_base & 15u) == 0, "aur_set_background: the base frame must be 16-byte aligned");
+    ctx->d_base = d_base;
+    ctx->base_w = W;
+    ctx->base_h = H;
+    return AUR_OK;
+}
+
+int aur_check_background(aur_ctx* ctx, const char* who, int W, int H) {
+    AUR_REQUIRE(ctx->d_base == nullptr || (ctx->base_w == W && ctx->base_h == H),
+                "%s: the background was set for %dx%d frames, not %dx%d", who, ctx->base_w, ctx->base_h, W, H);
+    return AUR_OK;
+}
+
 extern "C" int aur_get_window(aur_ctx* ctx, float* h_window) {
     AUR_REQUIRE(ctx && h_window, "aur_get_window: null argument");
     memcpy(h_window, ctx->h_window, sizeof(float) * AUR_FFT_SIZE);

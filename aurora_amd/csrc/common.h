@@ -39,12 +39,17 @@ struct aur_ctx {
     int fill_mode;         // AUR_FILL_MODE=1: aur_raster_spans_ws / aur_raster_planes use the row-tile kernels (A/B runs)
     int stft_fpw;          // AUR_STFT_FPW: frames per wave of the STFT kernel
     void* d_static_work;   // this device's address of raster.hip's file-scope work area (aur_raster_spans_static)
+    const uint8_t* d_base; // aur_set_background: uint8 [base_h][base_w][3] every frame starts from (NULL: plain (13,13,18))
+    int base_w, base_h;
     void* d_rows;          // AUR_ROWS_BYTES of per-(frame, row) disc intervals + AUR_ROWS_FLAGS per-frame flags: the small
                            // table aur_raster_planes' linear fill looks up (radial.hip); allocated in aur_create
 };
 
 #define AUR_ROWS_BYTES (8 * 1024 * 1024)
 #define AUR_ROWS_FLAGS 65536
+
+// abi.hip: a background is set for exactly this frame size (or none is set)
+int aur_check_background(aur_ctx* ctx, const char* who, int W, int H);
 
 // raster.hip: resolves the device address of the static work area for ctx->device (which must be current)
 int aur_raster_static_init(aur_ctx* ctx);

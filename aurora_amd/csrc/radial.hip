@@ -707,9 +707,11 @@ __global__ __launch_bounds__(256) void disc_rows_kernel(const uint32_t* __restri
     }
 }
 
+template <bool BASE>
 __global__ __launch_bounds__(256) void raster_fill_rows_kernel(const uint32_t* __restrict__ rows, int rows_static, int H,
                                                                int nu4, int upf, float inv_upf, float inv_nu4, int head,
-                                                               unsigned total, uint4* __restrict__ frames) {
+                                                               unsigned total, const uint4* __restrict__ base,
+                                                               uint4* __restrict__ frames) {
     const unsigned gi = blockIdx.x * 256u + threadIdx.x;
     if (gi < (unsigned)head) return;
     const unsigned g = gi - (unsigned)head;
@@ -738,22 +740,41 @@ __global__ __launch_bounds__(256) void raster_fill_rows_kernel(const uint32_t* _
     const int ph = col % 3, c0 = (16 * col) / 3;
     constexpr uint32_t D0 = kBg24 | (kBg24 << 24), D1 = (kBg24 >> 8) | (kBg24 << 16), D2 = (kBg24 >> 16) | (kBg24 << 8);
     uint4 o;
-    o.x = ph == 0 ? D0 : (ph == 1 ? D1 : D2);
-    o.y = ph == 0 ? D1 : (ph == 1 ? D2 : D0);
-    o.z = ph == 0 ? D2 : (ph == 1 ? D0 : D1);
-    o.w = o.x;
+    if (BASE) {                                          // aur_set_background: the frame starts from the composed image
+        o = base[u];
+    } else {
+        o.x = ph == 0 ? D0 : (ph == 1 ? D1 : D2);
+        o.y = ph == 0 ? D1 : (ph == 1 ? D2 : D0);
+        o.z = ph == 0 ? D2 : (ph == 1 ? D0 : D1);
+        o.w = o.x;
+    }
     if (c0 < x1 && c0 + 6 > x0) {
         uint32_t P[6];
+        if (BASE) {
+            uint32_t M[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) P[c] = (c0 + c >= x0 && c0 + c < x1) ? kDisc24 : kBg24;
-        o = pack_rgb16(P, ph);
+            for (int c = 0; c < 6; ++c) {
+                M[c] = (c0 + c >= x0 && c0 + c < x1) ? 0x00ffffffu : 0u;
+                P[c] = kDisc24 & M[c];
+            }
+            const uint4 mk = pack_rgb16(M, ph), pv = pack_rgb16(P, ph);
+            o.x = (o.x & ~mk.x) | pv.x;
+            o.y = (o.y & ~mk.y) | pv.y;
+            o.z = (o.z & ~mk.z) | pv.z;
+            o.w = (o.w & ~mk.w) | pv.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) P[c] = (c0 + c >= x0 && c0 + c < x1) ? kDisc24 : kBg24;
+            o = pack_rgb16(P, ph);
+        }
     }
     aur_store_frame16(frames + g, o);
 }
 
 // Rewrites the six 16-byte columns of plane word i of frame f (32 pixels = 96 bytes) when a bit of it must be painted.
+// rmw: pass 1 wrote a background image under the word, so the pixels that are not painted keep what the frame holds.
 __device__ __forceinline__ void patch_word(uint32_t sb, const uint32_t* __restrict__ disc_frame, bool disc_here, long i,
-                                           uint32_t pen, uint4* __restrict__ frame) {
+                                           uint32_t pen, uint4* __restrict__ frame, bool rmw) {
     uint32_t db = 0u;
     if (disc_here || sb != 0u) db = disc_frame[i];                   // the disc is painted last: it covers the stroke
     if (sb == 0u && !(disc_here && db != 0u)) return;
@@ -764,6 +785,23 @@ __device__ __forceinline__ void patch_word(uint32_t sb, const uint32_t* __restri
         const int c0 = (16 * k) / 3;                                  // 0, 5, 10, 16, 21, 26
         if (((need >> c0) & 0x3fu) == 0u) continue;                   // this 16-byte column is already right
         uint32_t P[6];
+        if (rmw) {
+            uint32_t M[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int b = c0 + c;                                 // <= 31
+                M[c] = ((need >> b) & 1u) ? 0x00ffffffu : 0u;
+                P[c] = (((db >> b) & 1u) ? kDisc24 : pen) & M[c];
+            }
+            const uint4 mk = pack_rgb16(M, k % 3), pv = pack_rgb16(P, k % 3);
+            uint4 o = dst[k];
+            o.x = (o.x & ~mk.x) | pv.x;
+            o.y = (o.y & ~mk.y) | pv.y;
+            o.z = (o.z & ~mk.z) | pv.z;
+            o.w = (o.w & ~mk.w) | pv.w;
+            dst[k] = o;
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             const int b = c0 + c;                                     // <= 31
@@ -780,7 +818,7 @@ __global__ __launch_bounds__(256) void raster_patch_planes_kernel(const uint32_t
                                                                   const uint32_t* __restrict__ disc,
                                                                   const uint32_t* __restrict__ rows,
                                                                   const uint32_t* __restrict__ pen_rgb, int words,
-                                                                  int W32, int H, int disc_static,
+                                                                  int W32, int H, int disc_static, int rmw,
                                                                   uint4* __restrict__ frames) {
     // words = H * W32 per frame; word i of frame f covers the uint4 columns 6 i .. 6 i + 5 of the frame (nu4 = 6 W32)
     const int f = blockIdx.y;
@@ -796,14 +834,14 @@ __global__ __launch_bounds__(256) void raster_patch_planes_kernel(const uint32_t
         const uint4 s4 = reinterpret_cast<const uint4*>(sf)[i4];
         const bool disc_here = rf[(4 * i4) / W32] == kRowMulti;       // W32 % 4 == 0: the four words share a row
         if (!disc_here && (s4.x | s4.y | s4.z | s4.w) == 0u) return;
-        patch_word(s4.x, df, disc_here, 4L * i4, pen, frame);
-        patch_word(s4.y, df, disc_here, 4L * i4 + 1, pen, frame);
-        patch_word(s4.z, df, disc_here, 4L * i4 + 2, pen, frame);
-        patch_word(s4.w, df, disc_here, 4L * i4 + 3, pen, frame);
+        patch_word(s4.x, df, disc_here, 4L * i4, pen, frame, rmw != 0);
+        patch_word(s4.y, df, disc_here, 4L * i4 + 1, pen, frame, rmw != 0);
+        patch_word(s4.z, df, disc_here, 4L * i4 + 2, pen, frame, rmw != 0);
+        patch_word(s4.w, df, disc_here, 4L * i4 + 3, pen, frame, rmw != 0);
     } else {
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i >= words) return;
-        patch_word(sf[i], df, rf[i / W32] == kRowMulti, i, pen, frame);
+        patch_word(sf[i], df, rf[i / W32] == kRowMulti, i, pen, frame, rmw != 0);
     }
 }
 
@@ -829,13 +867,19 @@ __global__ __launch_bounds__(256) void raster_fill_planes_px_kernel(const uint32
                                                                     const uint32_t* __restrict__ disc,
                                                                     const uint32_t* __restrict__ pen_rgb, int W, int H,
                                                                     int W32, int disc_static,
+                                                                    const uint8_t* __restrict__ base,
                                                                     uint8_t* __restrict__ frames) {
     const int f = blockIdx.z, row = blockIdx.y;
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= W) return;
     const uint32_t sb = (stroke[((long)f * H + row) * W32 + (x >> 5)] >> (x & 31)) & 1u;
     const uint32_t db = (disc[((long)(disc_static ? 0 : f) * H + row) * W32 + (x >> 5)] >> (x & 31)) & 1u;
-    const uint32_t c = db ? kDisc24 : (sb ? (pen_rgb[f] & 0x00ffffffu) : kBg24);
+    uint32_t c = kBg24;
+    if (base != nullptr) {
+        const uint8_t* b = base + ((long)row * W + x) * 3;
+        c = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+    }
+    c = db ? kDisc24 : (sb ? (pen_rgb[f] & 0x00ffffffu) : c);
     uint8_t* px = frames + (((size_t)f * H + row) * W + x) * 3;
     px[0] = (uint8_t)c;
     px[1] = (uint8_t)(c >> 8);
@@ -1337,19 +1381,24 @@ extern "C" int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, c
     AUR_REQUIRE(d_stroke_plane && d_disc_plane && d_pen_rgb && d_frames, "aur_raster_planes: null device pointer");
     AUR_REQUIRE(((uintptr_t)d_pen_rgb & 3u) == 0, "aur_raster_planes: misaligned d_pen_rgb");
     const int W32 = (W + 31) / 32;
-    if (W % 16 != 0 || ((uintptr_t)d_frames & 15u) != 0) {
+    if ((rc = aur_check_background(ctx, "aur_raster_planes", W, H))) return rc;
+    const long upf_chk = (long)(W * 3 / 16) * H;
+    const bool two_pass = W % 32 == 0 && ((uintptr_t)d_frames & 15u) == 0 && ctx->fill_mode != 1 && ctx->d_rows != nullptr &&
+                          upf_chk >= 256 && upf_chk < (1L << 26) && (long)n_frames * upf_chk + 256 < (1L << 31) &&
+                          (size_t)(disc_static ? 1 : n_frames) * H * 4 <= (size_t)AUR_ROWS_BYTES;
+    // odd widths and unaligned batches -- and a background image outside the two-pass fill's shapes -- go pixel by pixel
+    if (W % 16 != 0 || ((uintptr_t)d_frames & 15u) != 0 || (ctx->d_base != nullptr && !two_pass)) {
         hipLaunchKernelGGL(raster_fill_planes_px_kernel, dim3((W + 255) / 256, H, n_frames), dim3(256), 0,
                            (hipStream_t)stream, d_stroke_plane, d_disc_plane,
-                           reinterpret_cast<const uint32_t*>(d_pen_rgb), W, H, W32, disc_static ? 1 : 0, d_frames);
+                           reinterpret_cast<const uint32_t*>(d_pen_rgb), W, H, W32, disc_static ? 1 : 0, ctx->d_base,
+                           d_frames);
         AUR_CHECK_HIP(hipGetLastError());
         return AUR_OK;
     }
     const int nu4 = W * 3 / 16, nchunks = (nu4 + 63) / 64;
     const long upf_l = (long)nu4 * H;
     const int table_frames = disc_static ? 1 : n_frames;
-    if (W % 32 == 0 && ctx->fill_mode != 1 && ctx->d_rows != nullptr && upf_l >= 256 && upf_l < (1L << 26) &&
-        (long)n_frames * upf_l + 256 < (1L << 31) &&
-        (size_t)table_frames * H * 4 <= (size_t)AUR_ROWS_BYTES) {
+    if (two_pass) {
         hipStream_t st = (hipStream_t)stream;
         uint32_t* rows = reinterpret_cast<uint32_t*>(ctx->d_rows);
         hipLaunchKernelGGL(disc_rows_kernel, dim3((H + 3) / 4, table_frames), dim3(256), 0, st, d_disc_plane, H, W32, rows);
@@ -1357,17 +1406,25 @@ extern "C" int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, c
         const int head = (int)(((uintptr_t)d_frames & 4095u) / 16u);
         const unsigned total = (unsigned)n_frames * (unsigned)upf;
         const unsigned gfill = (unsigned)(((unsigned long)total + (unsigned)head + 255u) / 256u);
-        hipLaunchKernelGGL(raster_fill_rows_kernel, dim3(gfill), dim3(256), 0, st, rows, disc_static ? 1 : 0, H, nu4,
-                           upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, reinterpret_cast<uint4*>(d_frames));
+        const uint4* base = reinterpret_cast<const uint4*>(ctx->d_base);
+        const int rmw = base != nullptr ? 1 : 0;
+        if (base != nullptr)
+            hipLaunchKernelGGL(raster_fill_rows_kernel<true>, dim3(gfill), dim3(256), 0, st, rows, disc_static ? 1 : 0, H,
+                               nu4, upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, base,
+                               reinterpret_cast<uint4*>(d_frames));
+        else
+            hipLaunchKernelGGL(raster_fill_rows_kernel<false>, dim3(gfill), dim3(256), 0, st, rows, disc_static ? 1 : 0, H,
+                               nu4, upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, base,
+                               reinterpret_cast<uint4*>(d_frames));
         const int words = H * W32;
         if (W32 % 4 == 0 && ((uintptr_t)d_stroke_plane & 15u) == 0)
             hipLaunchKernelGGL(raster_patch_planes_kernel<true>, dim3((words / 4 + 255) / 256, n_frames), dim3(256), 0, st,
                                d_stroke_plane, d_disc_plane, rows, reinterpret_cast<const uint32_t*>(d_pen_rgb), words,
-                               W32, H, disc_static ? 1 : 0, reinterpret_cast<uint4*>(d_frames));
+                               W32, H, disc_static ? 1 : 0, rmw, reinterpret_cast<uint4*>(d_frames));
         else
             hipLaunchKernelGGL(raster_patch_planes_kernel<false>, dim3((words + 255) / 256, n_frames), dim3(256), 0, st,
                                d_stroke_plane, d_disc_plane, rows, reinterpret_cast<const uint32_t*>(d_pen_rgb), words,
-                               W32, H, disc_static ? 1 : 0, reinterpret_cast<uint4*>(d_frames));
+                               W32, H, disc_static ? 1 : 0, rmw, reinterpret_cast<uint4*>(d_frames));
         AUR_CHECK_HIP(hipGetLastError());
         return AUR_OK;
     }

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256) void raster_fill_kernel(const uint32_t* __rest
 template <int K>
 __global__ __launch_bounds__(256) void raster_fill_px_kernel(const uint32_t* __restrict__ spans,
                                                              const uint32_t* __restrict__ pen_rgb, int W, int H,
+                                                             const uint8_t* __restrict__ base,
                                                              uint8_t* __restrict__ frames) {
     const int f = blockIdx.z, row = blockIdx.y;
     const int px = blockIdx.x * 256 + threadIdx.x;
@@ -299,7 +300,12 @@ __global__ __launch_bounds__(256) void raster_fill_px_kernel(const uint32_t* __r
         const uint32_t v = sp[(long)k * W];
         lit |= ((uint32_t)row - (v & 0xffffu)) < ((v >> 16) - (v & 0xffffu));
     }
-    const uint32_t c = lit ? (pen_rgb[f] & 0x00ffffffu) : kBg24;
+    uint32_t c = kBg24;
+    if (base != nullptr) {          // aur_set_background: the frame starts from the composed background image
+        const uint8_t* b = base + ((long)row * W + px) * 3;
+        c = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+    }
+    if (lit) c = pen_rgb[f] & 0x00ffffffu;
     uint8_t* dst = frames + (((long)f * H + row) * (long)W + px) * 3;
     dst[0] = (uint8_t)c;
     dst[1] = (uint8_t)(c >> 8);
@@ -462,13 +468,17 @@ __global__ __launch_bounds__(256) void span_summary_kernel(const uint32_t* __res
     summary[idx] = s;
 }
 
-template <int K>
+// BASE: the frame starts from `base` (uint4 [upf], aur_set_background) instead of the plain (13,13,18) pattern: one more
+// 16-byte load per lane (the base frame is shared by every frame of the batch and stays in the last-level cache).
+template <int K, bool BASE>
 __global__ __launch_bounds__(256) void raster_fill_lin_kernel(const uint32_t* __restrict__ spans,
                                                               const uint2* __restrict__ summary,
                                                               const uint32_t* __restrict__ merged,
                                                               const uint32_t* __restrict__ pen_rgb, int W, int H,
                                                               int nu4, int upf, float inv_upf, float inv_nu4,
-                                                              int head, unsigned total, uint4* __restrict__ frames) {
+                                                              int head, unsigned total,
+                                                              const uint4* __restrict__ base,
+                                                              uint4* __restrict__ frames) {
     // g = index of this lane's uint4 in the batch; frames + g is 4 KB aligned for lane 0 of every workgroup
     const unsigned gi = blockIdx.x * 256u + threadIdx.x;
     if (gi < (unsigned)head) return;
@@ -499,21 +509,24 @@ __global__ __launch_bounds__(256) void raster_fill_lin_kernel(const uint32_t* __
     // background (13,13,18): dword j of the 16 bytes starts at byte (ph + j) % 3 of the repeating pattern 0d 0d 12
     constexpr uint32_t D0 = kBg24 | (kBg24 << 24), D1 = (kBg24 >> 8) | (kBg24 << 16), D2 = (kBg24 >> 16) | (kBg24 << 8);
     uint4 o;
-    o.x = ph == 0 ? D0 : (ph == 1 ? D1 : D2);
-    o.y = ph == 0 ? D1 : (ph == 1 ? D2 : D0);
-    o.z = ph == 0 ? D2 : (ph == 1 ? D0 : D1);
-    o.w = o.x;
+    if (BASE) {
+        o = base[u];
+    } else {
+        o.x = ph == 0 ? D0 : (ph == 1 ? D1 : D2);
+        o.y = ph == 0 ? D1 : (ph == 1 ? D2 : D0);
+        o.z = ph == 0 ? D2 : (ph == 1 ? D0 : D1);
+        o.w = o.x;
+    }
     if (((uint32_t)row - (s.x & 0xffffu)) < (s.x >> 16)) {
-        uint32_t P[6];
+        uint32_t lb = 0u;                                 // bit c: pixel column c0 + c is lit in this row
         if (s.y & kSumUniform) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) P[c] = ((s.y >> c) & 1u) ? pen : kBg24;
+            lb = s.y & 0x3fu;
         } else if (s.y & kSumMerged) {
             const uint32_t* m = merged + (long)f * W + (16 * col) / 3;
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const uint32_t v = m[c];
-                P[c] = (((uint32_t)row - (v & 0xffffu)) < ((v >> 16) - (v & 0xffffu))) ? pen : kBg24;
+                lb |= ((((uint32_t)row - (v & 0xffffu)) < ((v >> 16) - (v & 0xffffu))) ? 1u : 0u) << c;
             }
         } else {
             const uint32_t* sp = spans + (long)f * K * W + (16 * col) / 3;
@@ -525,10 +538,27 @@ __global__ __launch_bounds__(256) void raster_fill_lin_kernel(const uint32_t* __
                     const uint32_t v = sp[(long)k * W + c];
                     lit |= ((uint32_t)row - (v & 0xffffu)) < ((v >> 16) - (v & 0xffffu));
                 }
-                P[c] = lit ? pen : kBg24;
+                lb |= (lit ? 1u : 0u) << c;
             }
         }
-        o = pack_rgb16(P, ph);
+        uint32_t P[6];
+        if (BASE) {
+            uint32_t M[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                M[c] = ((lb >> c) & 1u) ? 0x00ffffffu : 0u;
+                P[c] = pen & M[c];
+            }
+            const uint4 mk = pack_rgb16(M, ph), pv = pack_rgb16(P, ph);
+            o.x = (o.x & ~mk.x) | pv.x;
+            o.y = (o.y & ~mk.y) | pv.y;
+            o.z = (o.z & ~mk.z) | pv.z;
+            o.w = (o.w & ~mk.w) | pv.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) P[c] = ((lb >> c) & 1u) ? pen : kBg24;
+            o = pack_rgb16(P, ph);
+        }
     }
     aur_store_frame16(frames + g, o);
 }
@@ -641,6 +671,7 @@ extern "C" int aur_raster_spans_ws(aur_ctx* ctx, const uint32_t* d_spans, int K,
     if (d_work == nullptr || ctx->fill_mode == 1 || !raster_lin_ok(n_frames, W, H, d_frames))
         return aur_raster_spans(ctx, d_spans, K, d_pen_rgb, n_frames, W, H, d_frames, stream);
     if (n_frames == 0) return AUR_OK;
+    if ((rc = aur_check_background(ctx, "aur_raster_spans_ws", W, H))) return rc;
     AUR_REQUIRE(d_spans && d_pen_rgb && d_frames, "aur_raster_spans_ws: null device pointer");
     AUR_REQUIRE(K == 2 || K == 5, "aur_raster_spans_ws: K=%d unsupported (2 or 5)", K);
     AUR_REQUIRE(((uintptr_t)d_pen_rgb & 3u) == 0, "aur_raster_spans_ws: misaligned device pointer");
@@ -659,12 +690,16 @@ extern "C" int aur_raster_spans_ws(aur_ctx* ctx, const uint32_t* d_spans, int K,
     const unsigned total = (unsigned)n_frames * (unsigned)upf;
     const unsigned gfill = (unsigned)(((unsigned long)total + (unsigned)head + 255u) / 256u);
     uint4* out = reinterpret_cast<uint4*>(d_frames);                   // lane 0 of workgroup b stores at out + 256 b - head
-    if (K == 2)
-        hipLaunchKernelGGL(raster_fill_lin_kernel<2>, dim3(gfill), dim3(256), 0, st, d_spans, summary, merged, pen, W, H,
-                           nu4, upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, out);
-    else
-        hipLaunchKernelGGL(raster_fill_lin_kernel<5>, dim3(gfill), dim3(256), 0, st, d_spans, summary, merged, pen, W, H,
-                           nu4, upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, out);
+    const uint4* base = reinterpret_cast<const uint4*>(ctx->d_base);   // 16-byte aligned (aur_set_background)
+#define AUR_LAUNCH_LIN(KK, BB)                                                                                          \
+    hipLaunchKernelGGL((raster_fill_lin_kernel<KK, BB>), dim3(gfill), dim3(256), 0, st, d_spans, summary, merged, pen, W, \
+                       H, nu4, upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, base, out)
+    if (K == 2) {
+        if (base) AUR_LAUNCH_LIN(2, true); else AUR_LAUNCH_LIN(2, false);
+    } else {
+        if (base) AUR_LAUNCH_LIN(5, true); else AUR_LAUNCH_LIN(5, false);
+    }
+#undef AUR_LAUNCH_LIN
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }
@@ -721,12 +756,14 @@ extern "C" int aur_raster_spans(aur_ctx* ctx, const uint32_t* d_spans, int K, co
         aur_set_error("aur_raster_spans: K=%d unsupported (2 or 5)", K);
         return AUR_EINVAL;
     }
-    if (W % 4 != 0 || ((uintptr_t)d_frames & 3u) != 0 || ((uintptr_t)d_spans & 15u) != 0) {   // any width, any alignment
+    if ((rc = aur_check_background(ctx, "aur_raster_spans", W, H))) return rc;
+    // any width, any alignment -- and every frame that starts from a background image outside the linear fill's shapes
+    if (ctx->d_base != nullptr || W % 4 != 0 || ((uintptr_t)d_frames & 3u) != 0 || ((uintptr_t)d_spans & 15u) != 0) {
         const dim3 grid((unsigned)((W + 255) / 256), (unsigned)H, (unsigned)n_frames);
         if (K == 2)
-            hipLaunchKernelGGL(raster_fill_px_kernel<2>, grid, dim3(256), 0, st, d_spans, pen, W, H, d_frames);
+            hipLaunchKernelGGL(raster_fill_px_kernel<2>, grid, dim3(256), 0, st, d_spans, pen, W, H, ctx->d_base, d_frames);
         else
-            hipLaunchKernelGGL(raster_fill_px_kernel<5>, grid, dim3(256), 0, st, d_spans, pen, W, H, d_frames);
+            hipLaunchKernelGGL(raster_fill_px_kernel<5>, grid, dim3(256), 0, st, d_spans, pen, W, H, ctx->d_base, d_frames);
         AUR_CHECK_HIP(hipGetLastError());
         return AUR_OK;
     }

@@ -68,6 +68,9 @@ class RadialConfig:
     feather_audio_amount: int = 0
     feather_sensitivity: float = 2.0
     waveform_sensitivity: float = 1.0
+    center_image_path: str | None = None     # rt_widget.py:226-240; None / unreadable file: the (30, 30, 40) fill
+    center_image_zoom: int = 100             # rt_widget.py:248-254
+    center_motion: int = 0                   # rt_widget.py:256-262
 
     @classmethod
     def from_view_state(cls, vs, sensitivity=1.0):
@@ -85,7 +88,16 @@ class RadialConfig:
         c.feather_audio_enabled = bool(vs.get("feather_audio_enabled", False))
         c.feather_audio_amount = max(0, min(100, int(vs.get("feather_audio_amount", 0))))
         c.waveform_sensitivity = max(0.05, float(sensitivity))
+        c.center_motion = max(0, min(100, int(vs.get("center_motion", 0))))            # exporter.py:164
+        if "center_image_zoom" in vs:
+            c.center_image_zoom = max(50, min(250, int(vs.get("center_image_zoom", 100))))   # exporter.py:165-166
+        c.center_image_path = vs.get("center_image_path") or None                      # exporter.py:171-177
         return c
+
+    @property
+    def disc_static(self):
+        """The envelope is the same circle in every frame (rt_widget.py:1038 reduces to r = inner)."""
+        return self.edge_waviness == 0 and not (self.feather_audio_enabled and self.feather_audio_amount > 0)
 
     # ring lengths after mirror / _smooth_closed #1 / _smooth_closed #2 (rt_widget.py:946-962, :1125)
     @property
@@ -307,7 +319,8 @@ class RadialPrep:
     state: "torch.Tensor"        # float64 [L1]: EMA state after the last frame
     cos_sin: "torch.Tensor"      # float64 [L2 + 1, 2]
     cos_sin360: "torch.Tensor"   # float64 [361, 2]
-    static_disc: dict = None     # (W, H) -> int32 [1, H, W32] disc plane when the envelope is frame-independent
+    static_disc: dict = None     # (W, H) -> what a frame-independent disc needs (HipExportEngine._static_disc)
+    image: "torch.Tensor | None" = None   # centre image, premultiplied 0xAARRGGBB int32 [h, w] on the device
 
 
 def _ptr(t):
@@ -365,6 +378,7 @@ class HipExportEngine:
         self.lib = self.ctx.lib
         self._tables = {}
         self._work = None
+        self._base = None
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):
@@ -560,7 +574,49 @@ class HipExportEngine:
             self._tables[key] = (torch.from_numpy(angle_table(cfg.L2, cfg.radial_rotation_deg)).to(self.device),
                                    torch.from_numpy(angle_table(360, cfg.radial_rotation_deg)).to(self.device))
         cs, cs360 = self._tables[key]
-        return RadialPrep(cfg, vals1, st_t, cs, cs360, {})
+        return RadialPrep(cfg, vals1, st_t, cs, cs360, {}, self._center_image(cfg.center_image_path))
+
+    def _center_image(self, path):
+        """Device copy of the centre image, decoded once per engine; None when there is none or it cannot be read
+        (`set_center_image` returns False and the disc keeps its plain fill, rt_widget.py:226-242)."""
+        if not path:
+            return None
+        key = ("center_image", str(path))
+        if key not in self._tables:
+            from .images import load_image_rgba, premultiply_argb
+            try:
+                self._tables[key] = self.upload_image(premultiply_argb(load_image_rgba(path)))
+            except Exception as e:                                   # noqa: BLE001 - any decode failure: no image
+                import logging
+                logging.getLogger(__name__).warning("centre image %r not loaded: %s", path, e)
+                self._tables[key] = None
+        return self._tables[key]
+
+    # ------------------------------------------------------------------ background image
+    def compose_background(self, bg, W: int, H: int):
+        """The frame every export frame starts from when a background image is set: uint8 [H, W, 3] on the device
+        (`paint_frame` rt_widget.py:829-830 -> `_draw_background` :505-545), or None when the file cannot be read
+        (`QImage(path).isNull()`: the reference then draws no background, :508-509)."""
+        from .images import load_image_rgba, premultiply_argb
+        try:
+            img = self.upload_image(premultiply_argb(load_image_rgba(bg.path)))
+        except Exception as e:                                       # noqa: BLE001
+            import logging
+            logging.getLogger(__name__).warning("background image %r not loaded: %s", bg.path, e)
+            return None
+        ih, iw = int(img.shape[0]), int(img.shape[1])
+        sw, sh, tile, x, y, dim_alpha = bg.plan(iw, ih, W, H)
+        scaled = img if tile else self.scale_image(img, sw, sh)
+        base = self.empty((H, W, 3), self.torch.uint8)
+        _lib.check(self.lib.aur_compose_background(self.ctx.handle, _ptr(scaled), sw, sh, int(tile), int(x), int(y),
+                                                   int(dim_alpha), W, H, _ptr(base), self.stream()),
+                   "aur_compose_background")
+        return base
+
+    def set_background(self, base, W: int = 0, H: int = 0):
+        """Frames rendered from now on start from ``base`` uint8 [H, W, 3] (None: the plain (13, 13, 18) fill)."""
+        _lib.check(self.lib.aur_set_background(self.ctx.handle, _ptr(base), int(W), int(H)), "aur_set_background")
+        self._base = base
 
     def carried_radial_state(self, track: Track, frame_begin: int, cfg: RadialConfig, chunk: int = 16384):
         """EMA state of the radial ring in front of ``frame_begin`` (analysis-only pre-pass over [0, frame_begin))."""
@@ -618,7 +674,19 @@ class HipExportEngine:
         enable = (sc.energy[first:first + count] >= float(fill.threshold)).to(torch.uint8)     # rt_widget.py:857
         _lib.check(self.lib.aur_plane_exclude(h, _ptr(plane), _ptr(stroke), _ptr(disc), int(bool(disc_static)),
                                               _ptr(enable), count, W, H, st), "aur_plane_exclude")
-        return self.blend_planes(plane, bytes(fill.colour_over_background()) + b"\xff", frames)
+        if self._base is None:
+            # painted straight onto the plain background: the result is one colour, composed on the host
+            return self.blend_planes(plane, bytes(fill.colour_over_background()) + b"\xff", frames)
+        # over a background image the blend is per pixel
+        if fill.blend == "add":
+            pm = torch.tensor([_div255(int(c) * int(fill.rgba[3])) for c in fill.rgba[:3]] + [0], dtype=torch.uint8,
+                              device=self.device).repeat(count, 1).reshape(count, 1, 4).contiguous()
+            _lib.check(self.lib.aur_add_planes(h, _ptr(plane), 1, _ptr(pm), None, None, 1, count, W, H, _ptr(frames), st),
+                       "aur_add_planes")
+            return frames
+        if fill.blend == "multiply":
+            raise NotImplementedError("radial_fill_blend 'multiply' over a background image is not implemented")
+        return self.blend_planes(plane, bytes(int(v) for v in fill.rgba), frames)
 
     def apply_shadow(self, shadow: ShadowConfig, verts, closed: bool, excl_a, excl_b, excl_b_static, frames,
                      round_join: bool = False, half_width=None, offset=None):
@@ -707,13 +775,123 @@ class HipExportEngine:
             self.stream()), "aur_envelope_vertices")
         return env
 
+    # ---- centre disc: antialiased clip + fill / centre image (rt_widget.py:1056-1096) ----------------------------------
+    DISC_ARGB = (255 << 24) | (30 << 16) | (30 << 8) | 40                   # QColor(30, 30, 40), rt_widget.py:1092/1094
+
+    @staticmethod
+    def disc_box(W: int, H: int, static: bool):
+        """Pixel box the envelope path lies in.  r = inner + g (r_max - inner) with g = tanh(1.25 g0) / tanh(1.25) <=
+        1 / tanh(1.25) (rt_widget.py:1040-1044), so r <= 0.22 m + 0.26 m / tanh(1.25) < 0.5266 m, m = min(w, h); a
+        frame-independent disc has r = inner = 0.22 m."""
+        m = min(W, H)
+        r = (0.22 * m if static else 0.5266 * m) + 3.0
+        cx, cy = W / 2.0, H / 2.0
+        x0, y0 = max(0, int(np.floor(cx - r))), max(0, int(np.floor(cy - r)))
+        x1, y1 = min(W, int(np.ceil(cx + r)) + 1), min(H, int(np.ceil(cy + r)) + 1)
+        return x0, y0, x1 - x0, y1 - y0
+
+    def upload_image(self, argb_pm: np.ndarray):
+        """Premultiplied 0xAARRGGBB uint32 [h, w] -> device tensor (int32 view of the same bits)."""
+        a = np.ascontiguousarray(argb_pm, dtype=np.uint32)
+        return self.torch.from_numpy(a.view(np.int32)).to(self.device)
+
+    def scale_image(self, img, dw: int, dh: int):
+        """QImage.scaled(dw, dh, IgnoreAspectRatio, SmoothTransformation) of a device image int32 [h, w]."""
+        sh, sw = int(img.shape[0]), int(img.shape[1])
+        if (dw, dh) == (sw, sh):
+            return img                                                    # QImage::scaled returns *this
+        out = self.empty((dh, dw), self.torch.int32)
+        _lib.check(self.lib.aur_image_scale(self.ctx.handle, _ptr(img), sw, sh, _ptr(out), int(dw), int(dh),
+                                            self.stream()), "aur_image_scale")
+        return out
+
+    def disc_composite(self, env, env_static: bool, count: int, W: int, H: int, box, frames=None, source=None,
+                       skip_full=False, full_plane=None):
+        """aur_disc_composite on ``frames`` uint8 [count, H, W, 3] (in place) and / or into ``full_plane``."""
+        src = source if source is not None else _lib.DiscSource(0, self.DISC_ARGB, None, 0, 0, None, 0)
+        _lib.check(self.lib.aur_disc_composite(
+            self.ctx.handle, _ptr(env), int(env.shape[1]), int(bool(env_static)), int(count), W, H, *box, C.byref(src),
+            int(bool(skip_full)), _ptr(full_plane), _ptr(frames), self.stream()), "aur_disc_composite")
+        return frames
+
+    def _static_disc(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int):
+        """Everything a frame-independent disc needs, once per frame size: its envelope, box, the bit plane of its fully
+        covered pixels (painted by the plane fill; what later translucent layers must leave alone) and the list of its
+        partially covered pixels with their effective coverage (fill x clip)."""
+        torch = self.torch
+        key = (W, H)
+        if key not in prep.static_disc:
+            W32 = (W + 31) // 32
+            env = self._envelope(prep, an, sc, W, H, first, 1)
+            box = self.disc_box(W, H, True)
+            full = torch.zeros((1, H, W32), dtype=torch.int32, device=self.device)
+            # coverage read-out: white at the disc's effective coverage on a black frame leaves exactly that coverage
+            probe = torch.zeros((1, H, W, 3), dtype=torch.uint8, device=self.device)
+            white = _lib.DiscSource(0, 0xFFFFFFFF, None, 0, 0, None, 0)
+            self.disc_composite(env, True, 1, W, H, box, frames=probe, source=white, full_plane=full)
+            ce = probe[0, :, :, 0].reshape(-1)
+            idx = torch.nonzero((ce > 0) & (ce < 255)).reshape(-1)
+            entry = dict(env=env, box=box, full=full, edge_index=idx.to(torch.int32).contiguous(),
+                         edge_cov=ce[idx].contiguous(), placement=None, scaled=None)
+            if prep.image is not None:
+                ih, iw = int(prep.image.shape[0]), int(prep.image.shape[1])
+                if prep.cfg.center_motion == 0:
+                    # the placement does not depend on the frame either: scale the image once
+                    pl = self.image_placement(prep, env, True, sc, first, 1)
+                    ow, oh = (int(v) for v in pl[0, :2].cpu().numpy())
+                    entry["placement"] = pl
+                    entry["scaled"] = self.scale_image(prep.image, ow, oh)
+            prep.static_disc[key] = entry
+        return prep.static_disc[key]
+
+    def image_placement(self, prep: RadialPrep, env, env_static: bool, sc: Scan, first: int, count: int):
+        """int32 [count, 4] = out_w, out_h, dx, dy of the centre image (rt_widget.py:1065-1088)."""
+        cfg = prep.cfg
+        ih, iw = int(prep.image.shape[0]), int(prep.image.shape[1])
+        out = self.empty((count, 4), self.torch.int32)
+        _lib.check(self.lib.aur_center_image_placement(
+            self.ctx.handle, _ptr(env), int(env.shape[1]), int(bool(env_static)), _ptr(sc.energy[first:first + count]),
+            _ptr(sc.phase[first:first + count]), count, iw, ih, int(cfg.center_image_zoom), int(cfg.center_motion),
+            _ptr(out), self.stream()), "aur_center_image_placement")
+        return out
+
+    def draw_disc(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int, frames):
+        """The centre disc of frames first .. first + count on ``frames`` (in place), after everything the reference
+        paints before it (rt_widget.py:1056-1096)."""
+        cfg = prep.cfg
+        if cfg.disc_static:
+            sd = self._static_disc(prep, an, sc, W, H, first)
+            if prep.image is None:
+                # interior painted by the plane fill from sd["full"]; the rim is a short list of blended pixels
+                n = int(sd["edge_index"].numel())
+                _lib.check(self.lib.aur_blend_pixels(self.ctx.handle, _ptr(sd["edge_index"]), _ptr(sd["edge_cov"]), n,
+                                                     self.DISC_ARGB, count, W, H, _ptr(frames), self.stream()),
+                           "aur_blend_pixels")
+                return frames
+            if sd["scaled"] is not None:
+                sc_img = sd["scaled"]
+                src = _lib.DiscSource(2, 0, sc_img.data_ptr(), int(sc_img.shape[1]), int(sc_img.shape[0]),
+                                      sd["placement"].data_ptr(), 1)
+                return self.disc_composite(sd["env"], True, count, W, H, sd["box"], frames=frames, source=src)
+            env, env_static, box = sd["env"], True, sd["box"]
+        else:
+            env, env_static, box = self._envelope(prep, an, sc, W, H, first, count), False, self.disc_box(W, H, False)
+        if prep.image is None:
+            return self.disc_composite(env, env_static, count, W, H, box, frames=frames)
+        pl = self.image_placement(prep, env, env_static, sc, first, count)
+        src = _lib.DiscSource(1, 0, prep.image.data_ptr(), int(prep.image.shape[1]), int(prep.image.shape[0]),
+                              pl.data_ptr(), 0)
+        return self.disc_composite(env, env_static, count, W, H, box, frames=frames, source=src)
+
     def radial_planes(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int,
                       planes_out=None):
-        """(stroke planes int32 [count, H, W32], disc planes int32 [count or 1, H, W32], disc_static).
+        """(stroke planes int32 [count, H, W32], disc plane int32 [1, H, W32], True).
 
-        With the export defaults (edge_waviness 0, audio term off) the disc envelope is the same circle in every
-        frame (rt_widget.py:1038 reduces to r = inner): its plane is rasterised once per frame size and reused."""
-        torch, cfg = self.torch, prep.cfg
+        The disc plane holds what the plane fill may paint in (30, 30, 40) ahead of the antialiased composite and what
+        translucent layers must leave alone: the fully covered pixels of a frame-independent disc that is filled with
+        the plain colour (export defaults: edge_waviness 0, audio term off, no centre image); nothing otherwise -- the
+        composite (draw_disc) then paints the whole disc."""
+        torch = self.torch
         W32 = (W + 31) // 32
         h, st = self.ctx.handle, self.stream()
         if planes_out is None:
@@ -721,19 +899,15 @@ class HipExportEngine:
         verts = self.radial_path_vertices(prep, sc, W, H, first, count)
         _lib.check(self.lib.aur_mask_stroke_closed(h, _ptr(verts), int(verts.shape[1]), count, W, H,
                                                    _ptr(planes_out[0]), st), "aur_mask_stroke_closed")
-        static = cfg.edge_waviness == 0 and not (cfg.feather_audio_enabled and cfg.feather_audio_amount > 0)
-        if static:
-            key = (W, H)
-            if key not in prep.static_disc:
-                env = self._envelope(prep, an, sc, W, H, first, 1)
-                plane = self.empty((1, H, W32), torch.int32)
-                _lib.check(self.lib.aur_mask_polygon(h, _ptr(env), 361, 1, W, H, _ptr(plane), st), "aur_mask_polygon")
-                prep.static_disc[key] = plane
-            return planes_out[0], prep.static_disc[key], True
-        env = self._envelope(prep, an, sc, W, H, first, count)
-        _lib.check(self.lib.aur_mask_polygon(h, _ptr(env), 361, count, W, H, _ptr(planes_out[1]), st),
-                   "aur_mask_polygon")
-        return planes_out[0], planes_out[1], False
+        if prep.cfg.disc_static and prep.image is None:
+            return planes_out[0], self._static_disc(prep, an, sc, W, H, first)["full"], True
+        return planes_out[0], self._no_disc_plane(W, H), True
+
+    def _no_disc_plane(self, W: int, H: int):
+        key = ("nodisc", W, H)
+        if key not in self._tables:
+            self._tables[key] = self.torch.zeros((1, H, (W + 31) // 32), dtype=self.torch.int32, device=self.device)
+        return self._tables[key]
 
     def fill_planes(self, planes, pen_rgb, W: int, H: int, out=None):
         stroke, disc, static = planes
@@ -768,6 +942,7 @@ class HipExportEngine:
         if want_shadow:
             env = self._envelope(prep, an, sc, W, H, first, count)
             self.apply_shadow(shadow, env, False, None, planes[1], planes[2], out)                # :1053-1054
+        self.draw_disc(prep, an, sc, W, H, first, count, out)                                     # :1056-1096
         if prep.cfg.feather_enabled:
             self.feather_blend(prep, an, sc, W, H, first, count, out)
         return out

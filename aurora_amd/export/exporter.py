@@ -31,6 +31,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from ..engine import FillConfig, GlowConfig, RadialConfig, ShadowConfig, get_engine, mode_kind, SUPPORTED_KINDS
+from ..images import BackgroundConfig
 from ..pipeline import FramePipeline
 
 logger = logging.getLogger(__name__)
@@ -128,9 +129,6 @@ class HipOffscreenRenderer:
         kind = mode_kind(self.mode)
         if kind not in SUPPORTED_KINDS:
             raise NotImplementedError(f"mode {self.mode!r} is not implemented on the HIP export path yet")
-        for key in ("background_path", "center_image_path"):
-            if view_state.get(key):
-                raise NotImplementedError(f"view_state[{key!r}] is not implemented on the HIP export path yet")
         radial = RadialConfig.from_view_state(view_state, self.sensitivity) if kind == "spectrum_radial" else None
 
         device = int(view_state.get("hip_device", 0) or 0)
@@ -158,7 +156,8 @@ class HipOffscreenRenderer:
                                    wire_format=str(view_state.get("hip_wire_format", "rgb24")),
                                    fill=FillConfig.from_view_state(view_state),
                                    shadow=ShadowConfig.from_view_state(view_state),
-                                   glow=GlowConfig.from_view_state(view_state))
+                                   glow=GlowConfig.from_view_state(view_state),
+                                   background=BackgroundConfig.from_view_state(view_state))
         self.wire_format = self._pipe.wire_format
         self._cache = None          # (first_frame, uint8 [n, H, W, 3] host array)
 

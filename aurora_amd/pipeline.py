@@ -72,7 +72,7 @@ class FramePipeline:
                  batch_frames: int | None = None, slots: int = 2, scan_params: _lib.ScanParams | None = None,
                  radial: "RadialConfig | None" = None, rotation_deg: float = 0.0, wire_format: str = "rgb24",
                  fill: "FillConfig | None" = None, shadow: "ShadowConfig | None" = None,
-                 glow: "GlowConfig | None" = None):
+                 glow: "GlowConfig | None" = None, background=None):
         self.eng = engine
         self.track = track
         self.mode = mode
@@ -105,6 +105,12 @@ class FramePipeline:
                                  (self.planes or self.kind == "waveform_linear")) else None
         # `_draw_glow_path` is only called for the closed paths (rt_widget.py:901, :980)
         self.glow = glow if (glow is not None and glow.active and self.planes) else None
+        # background image (`_draw_background`, rt_widget.py:505-545): composed once, every frame starts from it
+        self.background = background if (background is not None and background.active) else None
+        if (self.background is not None and self.fill is not None and self.fill.blend == "multiply"):
+            raise NotImplementedError("radial_fill_blend 'multiply' over a background image is not implemented")
+        self._base = None
+        self._base_done = False
         self._analysed = None
         self._radial_prep = None
         self._ring = None
@@ -137,6 +143,18 @@ class FramePipeline:
         return self._render(an, sc, first, count, out, spans_out)
 
     def _render(self, an, sc, first, count, out=None, scratch=None):
+        if self.background is not None and not self._base_done:
+            self._base = self.eng.compose_background(self.background, self.W, self.H)
+            self._base_done = True
+        # the base frame is a property of the context: every render states whose it is (pipelines share engines)
+        self.eng.set_background(self._base, self.W, self.H)
+        try:
+            return self._render_batch(an, sc, first, count, out, scratch)
+        finally:
+            if self._base is not None:
+                self.eng.set_background(None)
+
+    def _render_batch(self, an, sc, first, count, out=None, scratch=None):
         if self.radial is not None:
             return self.eng.render_radial(self._radial_prep, an, sc, self.W, self.H, first, count, out=out,
                                           planes_out=scratch, fill=self.fill, shadow=self.shadow, glow=self.glow)

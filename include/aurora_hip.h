@@ -321,6 +321,65 @@ int aur_add_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t*
 int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, const uint32_t* d_disc_plane, int disc_static,
                       const uint8_t* d_pen_rgb /*[F,4]*/, int n_frames, int W, int H, uint8_t* d_frames, void* stream);
 
+/* ---- antialiased centre disc, centre image, background image ---------------------------------- */
+
+/* What fills the centre disc of "Spectrum - Radial" (widgets/rt_widget.py:1060-1094).
+ * mode 0: `p.fillPath(path, QColor(30, 30, 40))` under `setClipPath(path)`: the constant premultiplied colour, coverage of
+ *         the fill multiplied with the coverage of the clip (Qt intersects the two span lists);
+ * mode 1: `p.drawImage(dx, dy, img.scaled(out_w, out_h, IgnoreAspectRatio, SmoothTransformation))` under the clip, scaled
+ *         per frame from d_image (premultiplied 0xAARRGGBB [img_h][img_w]); d_placement int32 [F or 1][4] = out_w, out_h,
+ *         dx, dy (aur_center_image_placement);
+ * mode 2: the same with d_image already scaled to placement's out_w x out_h (aur_image_scale; static placement). */
+typedef struct aur_disc_source {
+    int32_t mode;
+    uint32_t colour_argb_pm;
+    const uint32_t* d_image;
+    int32_t img_w, img_h;
+    const int32_t* d_placement;
+    int32_t placement_static;
+} aur_disc_source;
+
+/* QImage::scaled(dst_w, dst_h, Qt::IgnoreAspectRatio, Qt::SmoothTransformation) of a premultiplied ARGB32 image
+ * (rt_widget.py:567, :1090; Qt's qimagescale.cpp: 8-bit bilinear weights when an axis grows, 14-bit area average when it
+ * shrinks).  d_src uint32 [src_h][src_w], d_dst uint32 [dst_h][dst_w]. */
+int aur_image_scale(aur_ctx* ctx, const uint32_t* d_src, int src_w, int src_h, uint32_t* d_dst, int dst_w, int dst_h,
+                    void* stream);
+
+/* Placement of the centre image per frame (rt_widget.py:1065-1088): bounding rect of the clip path adjusted by 2 px,
+ * cover scale, `center_image_zoom`, `center_motion` zoom and jitter from the frame's energy and phase.
+ * d_verts float64 [F or 1 (verts_static)][n_vertices][2]; d_placement int32 [F][4] = out_w, out_h, dx, dy. */
+int aur_center_image_placement(aur_ctx* ctx, const double* d_verts, int n_vertices, int verts_static,
+                               const double* d_energy, const double* d_phase, int n_frames, int img_w, int img_h,
+                               int zoom_percent, int center_motion, int32_t* d_placement, void* stream);
+
+/* The centre disc with the reference's antialiasing (rt_widget.py:1056-1096): exact-area even-odd coverage of the
+ * envelope polygon per pixel (26.6 vertices, 1/256-pixel cells, 0..255) and Qt's premultiplied source-over with that
+ * coverage, in place on d_frames uint8 [F][H][W][3].  The polygon must lie inside the box (box_x, box_y, box_w, box_h).
+ * d_full_plane (optional) receives the bit plane uint32 [F][H][ceil(W/32)] of the pixels with full coverage (only the
+ * words of the box are written: clear it first); d_frames may be NULL when only that plane is wanted.  skip_full: in
+ * mode 0 the pixels of full coverage are left alone (the plane fill painted them already). */
+int aur_disc_composite(aur_ctx* ctx, const double* d_verts, int n_vertices, int verts_static, int n_frames, int W, int H,
+                       int box_x, int box_y, int box_w, int box_h, const aur_disc_source* src, int skip_full,
+                       uint32_t* d_full_plane, uint8_t* d_frames, void* stream);
+
+/* The same source-over for a frame-independent disc (the export default: no waviness, no audio term): its partially
+ * covered pixels as a list -- d_pixel_index uint32 [n] = y * W + x (every index < W * H: the caller's contract),
+ * d_coverage uint8 [n] = effective coverage -- blended in colour_argb_pm (premultiplied) into every frame. */
+int aur_blend_pixels(aur_ctx* ctx, const uint32_t* d_pixel_index, const uint8_t* d_coverage, int n_pixels,
+                     uint32_t colour_argb_pm, int n_frames, int W, int H, uint8_t* d_frames, void* stream);
+
+/* The frame every export frame starts from when a background image is set (`paint_frame` rt_widget.py:829-830,
+ * `_draw_bg_image` :519-545): fillRect (13,13,18), the (already scaled) premultiplied image drawn at (x, y) -- or tiled
+ * from (x, y) in steps of its size over the frame's own tiling range -- then fillRect(0, 0, w, h, QColor(0, 0, 0,
+ * dim_alpha)).  d_base uint8 [H][W][3]. */
+int aur_compose_background(aur_ctx* ctx, const uint32_t* d_image, int img_w, int img_h, int tile, int x, int y,
+                           int dim_alpha, int W, int H, uint8_t* d_base, void* stream);
+
+/* Sets (d_base != NULL) or clears (NULL) the base frame uint8 [H][W][3] that aur_raster_spans*, aur_raster_planes and
+ * their fallbacks paint on instead of the plain (13,13,18) background.  The pointer must stay valid until it is cleared
+ * or the context is destroyed; W, H must match the frames rendered afterwards. */
+int aur_set_background(aur_ctx* ctx, const uint8_t* d_base, int W, int H);
+
 /* ---- wire format ------------------------------------------------------------------------------- */
 
 /* Opt-in planar yuv420p wire format: the reference pipes rgb24 into FFmpeg

@@ -301,9 +301,10 @@ def frame_spans(mode, samples, spectrum, energy, w, h):
     raise NotImplementedError(f"oracle rasteriser does not cover mode {mode!r}")
 
 
-def render_frame(mode, samples, spectrum, energy, pen_rgb, w, h):
-    """One exported frame (rt_widget.py:821-852) -> uint8[h, w, 3]."""
-    return rasterize_spans(frame_spans(mode, samples, spectrum, energy, w, h), pen_rgb, w, h)
+def render_frame(mode, samples, spectrum, energy, pen_rgb, w, h, bg=BG):
+    """One exported frame (rt_widget.py:821-852) -> uint8[h, w, 3]; ``bg``: (13, 13, 18) or the composed background
+    image uint8 [h, w, 3] (compose_background)."""
+    return rasterize_spans(frame_spans(mode, samples, spectrum, energy, w, h), pen_rgb, w, h, bg)
 
 
 def psnr(a: np.ndarray, b: np.ndarray) -> float:
@@ -318,9 +319,8 @@ def psnr(a: np.ndarray, b: np.ndarray) -> float:
 #   * closed polyline stroke = one rectangle per segment (half-width 1, no caps: the path is closed) + one bevel
 #     triangle per vertex on the outer side of the turn; each primitive is a convex polygon whose intersection with
 #     the row line y = r + 0.5 is an x interval [xmin, xmax]; pixels ceil(xmin - .5) .. floor(xmax - .5) are lit;
-#   * the centre disc (rt_widget.py:1056-1096, QColor(30, 30, 40)) is an even-odd polygon fill sampled at pixel
-#     centres.  The reference fills it through an antialiased clip; antialiased edge blending is NOT reproduced
-#     (documented difference on the one-pixel rim of the disc; Qt coverage is parity-unpinned anyway);
+#   * the centre disc (rt_widget.py:1056-1096, QColor(30, 30, 40) or the centre image) is filled through an antialiased
+#     clip: coverage_aa / draw_center_disc at the end of this file (Qt coverage is parity-unpinned);
 #   * feather rings (rt_widget.py:1098-1117, only with feather_enabled, which has no UI control): six aliased even-odd
 #     fills of QColor(13, 13, 18, alpha) blended source-over in ring order with Qt's premultiplied ARGB32 arithmetic,
 #     d' = div255(c a) + div255(d (255 - a)), div255(x) = (x + (x >> 8) + 0x80) >> 8 (parity-unpinned like the rest).
@@ -483,23 +483,26 @@ def fill_colour_over_background(rgba, blend="normal", bg=BG):
     return tuple(out)
 
 
-def render_radial_frame(path_verts, env_verts, pen_rgb, w, h, bg=BG, rings=None, fill_rgb=None):
-    """One "Spectrum - Radial" frame: background, radial stroke in the pen colour, centre disc on top, then the
-    feather rings ``[(vertices, alpha)]`` (radial_ref.feather_ring_paths) blended in order."""
+def render_radial_frame(path_verts, env_verts, pen_rgb, w, h, bg=BG, rings=None, fill_rgb=None, image_pm=None,
+                        placement=None, base=None):
+    """One "Spectrum - Radial" frame: background (or the composed background image ``base``), radial stroke in the pen
+    colour, the antialiased centre disc on top (plain fill, or the centre image ``image_pm`` at ``placement``), then
+    the feather rings ``[(vertices, alpha)]`` (radial_ref.feather_ring_paths) blended in order."""
     frame = np.empty((h, w, 3), dtype=np.uint8)
-    frame[:] = np.asarray(bg, dtype=np.uint8)
+    frame[:] = np.asarray(bg, dtype=np.uint8) if base is None else base
     if fill_rgb is not None:                 # `_apply_fill` comes first (rt_widget.py:977)
         frame[unpack_mask(polygon_mask(path_verts, w, h), w)] = np.asarray(fill_rgb, dtype=np.uint8)
     frame[unpack_mask(stroke_mask_closed(path_verts, w, h), w)] = np.asarray(pen_rgb, dtype=np.uint8)
     if env_verts is not None:
-        frame[unpack_mask(polygon_mask(env_verts, w, h), w)] = np.asarray(DISC_RGB, dtype=np.uint8)
+        draw_center_disc(frame, env_verts, w, h, image_pm, placement)
     for verts, alpha in (rings or []):
         blend_solid(frame, unpack_mask(polygon_mask(verts, w, h), w), bg, alpha)
     return frame
 
 
 def render_wave_circular_frame(path_verts, pen_rgb, w, h, bg=BG):
-    """One "Waveform - Circular" frame (rt_widget.py:866-902): background and the stroked closed path."""
+    """One "Waveform - Circular" frame (rt_widget.py:866-902): background (colour or composed image) and the stroked
+    closed path."""
     frame = np.empty((h, w, 3), dtype=np.uint8)
     frame[:] = np.asarray(bg, dtype=np.uint8)
     frame[unpack_mask(stroke_mask_closed(path_verts, w, h), w)] = np.asarray(pen_rgb, dtype=np.uint8)
@@ -558,4 +561,313 @@ def apply_glow(frame, path_verts, energy, keep_bool, w, h, rgba=(0xA0, 0xFF, 0xF
     for width, alpha in glow_pens(energy, rgba, radius, strength, layers):
         m = unpack_mask(stroke_mask_closed(path_verts, w, h, half_width=width / 2.0, closed=True, round_join=True), w)
         add_solid(frame, m & keep_bool, rgba[:3], alpha)
+    return frame
+
+
+# ----------------------------------------------------------------------------- antialiased polygon coverage
+# `_draw_center_image_and_mask` turns QPainter.Antialiasing on before `setClipPath(path)` / `fillPath(path, ...)`
+# (widgets/rt_widget.py:1056-1058, :1092-1094): Qt's raster engine then rasterises the path with its gray-raster
+# (qgrayraster.c, the FreeType "smooth" rasteriser): vertices are rounded to 26.6 fixed point, scaled to 1/256 pixel, and
+# every pixel gets the exact signed area the outline covers of it, in 1/512 steps, folded by the fill rule and clamped to
+# 255.  Qt's source is not in the reference tree, so this layer is **parity unpinned**; the rule implemented here (and,
+# bit for bit, by csrc/image.hip) is that algorithm with one canonical rounding: where an edge crosses a pixel-row or
+# pixel-column boundary the crossing point is rounded DOWN to the 1/256 grid from the edge's own end points (FreeType
+# distributes the same remainders incrementally).  All arithmetic is integer, so the result does not depend on the order
+# in which edges are accumulated.
+
+def _fixed_26_6(v: float) -> int:
+    """qreal_to_fixed_26_6 = qRound(v * 64), then scaled to the gray raster's 1/256 pixel units."""
+    return int(math.floor(v * 64.0 + 0.5)) * 4
+
+
+def _cells_of_edge(x0, y0, x1, y1):
+    """(ex, ey, dcover, darea) of every pixel cell the edge (integers, 1/256 px) passes through."""
+    if y0 == y1:
+        return
+    sign = 1 if y1 > y0 else -1
+    if sign < 0:
+        x0, y0, x1, y1 = x1, y1, x0, y0            # canonical: upwards in y; the sign carries the direction
+    dx, dy = x1 - x0, y1 - y0                      # dy > 0
+    if x0 <= x1:
+        xl, yl_x, xr, yr_x = x0, y0, x1, y1        # canonical by x for the column crossings
+    else:
+        xl, yl_x, xr, yr_x = x1, y1, x0, y0
+    for ey in range(y0 >> 8, ((y1 - 1) >> 8) + 1):
+        ya = max(y0, ey << 8)
+        yb = min(y1, (ey + 1) << 8)
+        xa = x0 if ya == y0 else x0 + ((ya - y0) * dx) // dy
+        xb = x1 if yb == y1 else x0 + ((yb - y0) * dx) // dy
+        if xa == xb:
+            ex = xa >> 8
+            yield ex, ey, sign * (yb - ya), sign * (yb - ya) * 2 * (xa - (ex << 8))
+            continue
+        lo, hi = (xa, xb) if xa < xb else (xb, xa)
+        ylo, yhi = (ya, yb) if xa < xb else (yb, ya)   # y at the piece's left / right end
+        for ex in range(lo >> 8, ((hi - 1) >> 8) + 1):
+            cxa = max(lo, ex << 8)
+            cxb = min(hi, (ex + 1) << 8)
+
+            def y_at(x, x_end_lo=lo, x_end_hi=hi):
+                if x == x_end_lo:
+                    return ylo
+                if x == x_end_hi:
+                    return yhi
+                y = yl_x + ((x - xl) * (yr_x - yl_x)) // (xr - xl)
+                return min(max(y, ya), yb)
+            pya, pyb = y_at(cxa), y_at(cxb)
+            d = (pyb - pya) if xa < xb else (pya - pyb)        # upwards along the canonical direction
+            yield ex, ey, sign * d, sign * d * ((cxa - (ex << 8)) + (cxb - (ex << 8)))
+
+
+def coverage_aa(verts, w, h):
+    """uint8 [h, w]: antialiased even-odd coverage of the (implicitly closed) polygon ``verts`` float64 [n, 2]."""
+    V = np.asarray(verts, dtype=np.float64)
+    n = V.shape[0]
+    X = [_fixed_26_6(float(v)) for v in V[:, 0]]
+    Y = [_fixed_26_6(float(v)) for v in V[:, 1]]
+    cover = np.zeros((h, w + 1), dtype=np.int64)          # column 0: everything left of the frame
+    area = np.zeros((h, w), dtype=np.int64)
+    for e in range(n):
+        e1 = (e + 1) % n
+        for ex, ey, dc, da in _cells_of_edge(X[e], Y[e], X[e1], Y[e1]):
+            if ey < 0 or ey >= h or ex >= w:
+                continue
+            if ex < 0:
+                cover[ey, 0] += dc
+            else:
+                cover[ey, ex + 1] += dc
+                area[ey, ex] += da
+    acc = np.cumsum(cover, axis=1)[:, 1:]
+    val = np.abs(acc * 512 - area) >> 9
+    val &= 511
+    val = np.where(val > 256, 512 - val, val)
+    return np.minimum(val, 255).astype(np.uint8)
+
+
+def byte_mul(x, a):
+    """Qt's BYTE_MUL on one channel: x * a / 255 rounded the way qdrawhelper does."""
+    t = x * a
+    return (t + (t >> 8) + 0x80) >> 8
+
+
+def blend_cov(frame, src_rgba_pm, cov):
+    """comp_func_SourceOver with a per-pixel coverage (Qt raster engine, spans of an antialiased clip / fill):
+    s = BYTE_MUL(src, cov) on the premultiplied source, d' = s + BYTE_MUL(d, 255 - alpha(s)).  ``src_rgba_pm``
+    uint8 [h, w, 4] (or one (r, g, b, a)) premultiplied, ``cov`` uint8 [h, w]; in place on ``frame`` uint8 [h, w, 3]."""
+    c = cov.astype(np.uint32)[..., None]
+    src = np.broadcast_to(np.asarray(src_rgba_pm, dtype=np.uint32), frame.shape[:2] + (4,))
+    s = byte_mul(src, c)
+    d = frame.astype(np.uint32)
+    out = s[..., :3] + byte_mul(d, 255 - s[..., 3:4])
+    m = cov > 0
+    frame[m] = out[m].astype(np.uint8)
+    return frame
+
+
+def disc_fill_coverage(cov):
+    """`fillPath(path, colour)` under `setClipPath(path)` with antialiasing: the fill's coverage is intersected with the
+    clip's (qt_intersect_spans: qt_div_255(a * b)); both come from the same path."""
+    c = cov.astype(np.uint32)
+    return byte_mul(c, c).astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------- QImage.scaled(..., SmoothTransformation)
+# `img.scaled(out_w, out_h, Qt.IgnoreAspectRatio, Qt.SmoothTransformation)` (widgets/rt_widget.py:1090, :567) ends in
+# qSmoothScaleImage (Qt 6 src/gui/painting/qimagescale.cpp, the Imlib2 scaler) on a premultiplied ARGB32 image.  Restated
+# from that algorithm's published form (generic C path); Qt's source is not in the reference tree: **parity unpinned**.
+# Up-scaling an axis: 8-bit bilinear weights from 16.16 positions; down-scaling: area average with 14-bit weights.
+
+def _scale_points(s, d):
+    """(pos[d], ap[d], up) of one axis: source index and weight word per destination index."""
+    up = d >= s
+    inc = (s << 16) // d
+    pos = np.empty(d, dtype=np.int64)
+    ap = np.empty(d, dtype=np.int64)
+    if up:
+        val = (0x8000 * s) // d - 0x8000
+        for i in range(d):
+            p = val >> 16
+            pos[i] = max(0, p)
+            ap[i] = 0 if (p < 0 or p >= s - 1) else ((val >> 8) & 0xff)
+            val += inc
+    else:
+        cp = ((d << 14) + s - 1) // s
+        val = 0
+        for i in range(d):
+            pos[i] = val >> 16
+            ap[i] = (((0x10000 - (val & 0xffff)) * cp) >> 16) | (cp << 16)
+            val += inc
+    return pos, ap, up
+
+
+def _interp256(x, a, y, b):
+    return (x * a + y * b) >> 8          # INTERPOLATE_PIXEL_256 per channel
+
+
+def _area_axis(fetch, start, ap_word, limit):
+    """qt_qimageScaleAARGBA_helper along one axis: fetch(i) -> int64 [4]; returns the 14-bit weighted sum."""
+    xyap, c = int(ap_word) & 0xffff, int(ap_word) >> 16
+    i = start
+    acc = fetch(min(i, limit)) * xyap
+    j = (1 << 14) - xyap
+    while j > c:
+        i += 1
+        acc = acc + fetch(min(i, limit)) * c
+        j -= c
+    i += 1
+    acc = acc + fetch(min(i, limit)) * j
+    return acc
+
+
+def smooth_scale_pixel(img, dw, dh, x, y, _cache={}):
+    """One pixel (x, y) of ``img`` uint8 [sh, sw, 4] (premultiplied r, g, b, a) smooth-scaled to dw x dh -> int [4]."""
+    sh, sw = img.shape[:2]
+    key = (sw, sh, dw, dh)
+    if key not in _cache:
+        _cache.clear()
+        _cache[key] = (_scale_points(sw, dw), _scale_points(sh, dh))
+    (xpos, xap, xup), (ypos, yap, yup) = _cache[key]
+    px = lambda xx, yy: img[yy, xx].astype(np.int64)
+    sx, sy = int(xpos[x]), int(ypos[y])
+    if xup and yup:
+        xa, ya = int(xap[x]), int(yap[y])
+        if ya > 0:
+            if xa > 0:
+                top = _interp256(px(sx, sy), 256 - xa, px(sx + 1, sy), xa)
+                bot = _interp256(px(sx, sy + 1), 256 - xa, px(sx + 1, sy + 1), xa)
+                return _interp256(top, 256 - ya, bot, ya)
+            return _interp256(px(sx, sy), 256 - ya, px(sx, sy + 1), ya)
+        if xa > 0:
+            return _interp256(px(sx, sy), 256 - xa, px(sx + 1, sy), xa)
+        return px(sx, sy)
+    if xup and not yup:                       # qt_qimageScaleAARGBA_up_x_down_y
+        col = lambda xx: _area_axis(lambda i: px(xx, i), sy, yap[y], sh - 1)
+        r = col(sx)
+        xa = int(xap[x])
+        if xa > 0:
+            rr = col(sx + 1)
+            r = (r * (256 - xa) + rr * xa) >> 8
+        return r >> 14
+    if not xup and yup:                       # qt_qimageScaleAARGBA_down_x_up_y
+        row = lambda yy: _area_axis(lambda i: px(i, yy), sx, xap[x], sw - 1)
+        r = row(sy)
+        ya = int(yap[y])
+        if ya > 0:
+            rr = row(sy + 1)
+            r = (r * (256 - ya) + rr * ya) >> 8
+        return r >> 14
+    # down both: rows of x-averaged values (>> 4), weighted along y
+    rowsum = lambda yy: _area_axis(lambda i: px(i, yy), sx, xap[x], sw - 1) >> 4
+    return _area_axis(rowsum, sy, yap[y], sh - 1) >> 24
+
+
+def smooth_scale(img, dw, dh):
+    """Whole image; small sizes only (pure Python)."""
+    out = np.empty((dh, dw, 4), dtype=np.uint8)
+    for y in range(dh):
+        for x in range(dw):
+            out[y, x] = smooth_scale_pixel(img, dw, dh, x, y)
+    return out
+
+
+def premultiply(rgba):
+    """qPremultiply of uint8 [..., 4] straight-alpha (r, g, b, a)."""
+    p = np.asarray(rgba, dtype=np.uint32)
+    a = p[..., 3:4]
+    out = p.copy()
+    out[..., :3] = byte_mul(p[..., :3], a)
+    return out.astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------- centre image placement
+def center_image_placement(clip_verts, img_w, img_h, zoom=100, center_motion=0, energy=0.0, phase=0.0):
+    """(out_w, out_h, dx, dy) of `p.drawImage(dx, dy, img.scaled(out_w, out_h, ...))` (rt_widget.py:1065-1090).
+    path.boundingRect() of a polyline path = min / max of its vertices; QRectF.adjusted(-2, -2, 2, 2)."""
+    V = np.asarray(clip_verts, dtype=np.float64)
+    minx, maxx, miny, maxy = float(V[:, 0].min()), float(V[:, 0].max()), float(V[:, 1].min()), float(V[:, 1].max())
+    rx, ry, rw, rh = minx + -2.0, miny + -2.0, ((maxx - minx) + 2.0) - -2.0, ((maxy - miny) + 2.0) - -2.0
+    rect_w = max(1, int(rw))
+    rect_h = max(1, int(rh))
+    scale = max(rect_w / float(img_w), rect_h / float(img_h))
+    user_zoom = max(0.1, float(zoom) / 100.0)
+    scale *= user_zoom
+    cm = float(center_motion) / 100.0
+    if cm > 0.0:
+        motion_zoom = 1.0 + 0.12 * cm * (0.4 + 0.6 * energy) * (0.5 + 0.5 * np.sin(phase * 1.7))
+        scale *= max(0.1, motion_zoom)
+    out_w = int(max(1, round(img_w * scale)))
+    out_h = int(max(1, round(img_h * scale)))
+    cx_rect = rx + rw / 2.0
+    cy_rect = ry + rh / 2.0
+    dx = int(round(cx_rect - out_w / 2.0))
+    dy = int(round(cy_rect - out_h / 2.0))
+    if cm > 0.0:
+        j = int(cm * 6)
+        dx += int(round(j * np.sin(phase * 2.3)))
+        dy += int(round(j * np.cos(phase * 1.9)))
+    return out_w, out_h, dx, dy
+
+
+def draw_center_disc(frame, env_verts, w, h, image_pm=None, placement=None):
+    """The centre disc on ``frame`` (in place): antialiased clip of the envelope path, then either the (30, 30, 40) fill
+    (coverage of fill and clip multiplied) or the smooth-scaled centre image at ``placement`` = (out_w, out_h, dx, dy)."""
+    cov = coverage_aa(env_verts, w, h)
+    if image_pm is None:
+        return blend_cov(frame, DISC_RGB + (255,), disc_fill_coverage(cov))
+    out_w, out_h, dx, dy = placement
+    ys, xs = np.nonzero(cov)
+    src = np.zeros((h, w, 4), dtype=np.uint8)
+    keep = np.zeros((h, w), dtype=bool)
+    for y, x in zip(ys, xs):
+        ix, iy = int(x) - dx, int(y) - dy
+        if 0 <= ix < out_w and 0 <= iy < out_h:
+            src[y, x] = smooth_scale_pixel(image_pm, out_w, out_h, ix, iy)
+            keep[y, x] = True
+    return blend_cov(frame, src, np.where(keep, cov, 0).astype(np.uint8))
+
+
+# ----------------------------------------------------------------------------- background image
+def background_plan(img_w, img_h, w, h, scale_mode="fill", offset=(0, 0), dim_percent=0):
+    """(scaled_w, scaled_h, tile, x, y, dim_alpha) of `_draw_bg_image` / `_scaled_bg_for` (rt_widget.py:519-575);
+    QSize::scaled in Qt's integer arithmetic."""
+    mode = (scale_mode or "fill").lower()
+    d = max(0, min(100, int(dim_percent)))
+    dim_alpha = int(255 * (d / 100.0)) if d > 0 else 0
+    if mode == "tile":
+        return img_w, img_h, True, offset[0], offset[1], dim_alpha
+    if mode == "center":
+        sw, sh = img_w, img_h
+    elif mode == "stretch":
+        sw, sh = w, h
+    else:
+        rw = (h * img_w) // img_h
+        use_height = (rw <= w) if mode == "fit" else (rw >= w)
+        sw, sh = (rw, h) if use_height else (w, (w * img_h) // img_w)
+    sw, sh = max(sw, 1), max(sh, 1)
+    return sw, sh, False, (w - sw) // 2 + offset[0], (h - sh) // 2 + offset[1], dim_alpha
+
+
+def compose_background(image_pm, w, h, scale_mode="fill", offset=(0, 0), dim_percent=0):
+    """uint8 [h, w, 3]: fillRect (13, 13, 18), the background image (premultiplied uint8 [ih, iw, 4]) smooth-scaled and
+    drawn source-over at its place (or tiled), then the dim rectangle (rt_widget.py:829-830, :519-545)."""
+    ih, iw = image_pm.shape[:2]
+    sw, sh, tile, x0, y0, dim_alpha = background_plan(iw, ih, w, h, scale_mode, offset, dim_percent)
+    frame = np.empty((h, w, 3), dtype=np.uint8)
+    frame[:] = np.asarray(BG, dtype=np.uint8)
+    for y in range(h):
+        for x in range(w):
+            ix, iy = x - x0, y - y0
+            if tile:
+                if ix < 0 or iy < 0 or (ix // iw) * iw >= w or (iy // ih) * ih >= h:
+                    continue
+                s = image_pm[iy % ih, ix % iw].astype(np.int64)
+            else:
+                if not (0 <= ix < sw and 0 <= iy < sh):
+                    continue
+                s = (image_pm[iy, ix].astype(np.int64) if (sw, sh) == (iw, ih)
+                     else smooth_scale_pixel(image_pm, sw, sh, ix, iy))
+            d = frame[y, x].astype(np.int64)
+            frame[y, x] = (s[:3] + byte_mul(d, 255 - s[3])).astype(np.uint8)
+    if dim_alpha > 0:
+        frame[:] = byte_mul(frame.astype(np.int64), 255 - dim_alpha).astype(np.uint8)
     return frame

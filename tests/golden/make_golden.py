@@ -118,15 +118,78 @@ class QPainterPath:
     def lineTo(self, x, y): self.ops.append(("L", float(x), float(y)))
     def closeSubpath(self): self.ops.append(("Z", 0.0, 0.0))
 
+    def boundingRect(self):
+        # a path of straight segments: Qt's bounding rect is the min / max of its points
+        xs = [o[1] for o in self.ops if o[0] in "ML"]
+        ys = [o[2] for o in self.ops if o[0] in "ML"]
+        return QRectF(min(xs), min(ys), max(xs) - min(xs), max(ys) - min(ys))
+
+
+class QRectF:
+    """QRectF(x, y, w, h); adjusted() as qrect.h writes it: (xp + dx1, yp + dy1, w + dx2 - dx1, h + dy2 - dy1)."""
+
+    def __init__(self, x, y, w, h):
+        self._x, self._y, self._w, self._h = float(x), float(y), float(w), float(h)
+
+    def adjusted(self, dx1, dy1, dx2, dy2):
+        return QRectF(self._x + dx1, self._y + dy1, self._w + dx2 - dx1, self._h + dy2 - dy1)
+
+    def x(self): return self._x
+    def y(self): return self._y
+    def width(self): return self._w
+    def height(self): return self._h
+
+
+class QSize:
+    def __init__(self, w=0, h=0):
+        self.w, self.h = int(w), int(h)
+
+    def width(self): return self.w
+    def height(self): return self.h
+
+
+def _qsize_scaled(w, h, tw, th, aspect):
+    """QSize(w, h).scaled(QSize(tw, th), aspect) (qsize.cpp) followed by QImage::scaled's clamp to 1x1."""
+    if aspect == _Qt.IgnoreAspectRatio or w == 0 or h == 0:
+        nw, nh = tw, th
+    else:
+        rw = (th * w) // h
+        use_height = (rw <= tw) if aspect == _Qt.KeepAspectRatio else (rw >= tw)
+        nw, nh = (rw, th) if use_height else (tw, (tw * h) // w)
+    return max(nw, 1), max(nh, 1)
+
 
 class QImage:
+    """Recording image.  QImage(w, h, format) is a paint device; QImage(path) is "decoded" when the file name carries
+    its size (``memimg_<w>x<h>``), null otherwise; scaled() records its arguments and returns an image of the size Qt
+    would produce (no pixel is computed anywhere in this script)."""
     Format_RGB888 = 13
 
     def __init__(self, *a):
         self.args = a
         self.calls = []
+        self.size = None
+        self.scaled_from = None
+        if len(a) == 1 and isinstance(a[0], str):
+            import re
+            m = re.search(r"memimg_(\d+)x(\d+)", a[0])
+            if m:
+                self.size = (int(m.group(1)), int(m.group(2)))
+        elif len(a) >= 2:
+            self.size = (int(a[0]), int(a[1]))
 
-    def isNull(self): return len(self.args) < 2
+    def isNull(self): return self.size is None
+    def width(self): return self.size[0]
+    def height(self): return self.size[1]
+
+    def scaled(self, *a):
+        if isinstance(a[0], QSize):
+            tw, th, aspect, mode = a[0].w, a[0].h, a[1], a[2]
+        else:
+            tw, th, aspect, mode = int(a[0]), int(a[1]), a[2], a[3]
+        out = QImage(*_qsize_scaled(self.size[0], self.size[1], tw, th, aspect), 0)
+        out.scaled_from = (self.size, (tw, th), int(aspect), int(mode))
+        return out
 
 
 class QPainter:
@@ -159,6 +222,9 @@ class QPainter:
     def drawLine(self, x1, y1, x2, y2): self.calls.append(("drawLine", x1, y1, x2, y2))
     def drawPoint(self, x, y): self.calls.append(("drawPoint", x, y))
     def drawPath(self, path): self.calls.append(("drawPath", list(path.ops)))
+
+    def drawImage(self, x, y, img):
+        self.calls.append(("drawImage", int(x), int(y), img.size, img.scaled_from))
     def fillPath(self, path, col): self.calls.append(("fillPath", list(path.ops), col.tup()))
     def setClipPath(self, path): self.calls.append(("setClipPath", list(path.ops)))
     def translate(self, dx, dy): self.calls.append(("translate", float(dx), float(dy)))
@@ -204,8 +270,9 @@ def _install_stand_ins():
     pkg.__path__ = []
     core = types.ModuleType("PySide6.QtCore")
     core.Qt = _Qt
-    for n in ("QTimer", "QSize", "QRect", "QThread"):
+    for n in ("QTimer", "QRect", "QThread"):
         setattr(core, n, _dummy(n))
+    core.QSize = QSize
     core.QCoreApplication = type("QCoreApplication", (), {"instance": staticmethod(lambda: None)})
     gui = types.ModuleType("PySide6.QtGui")
     gui.QPainter, gui.QColor, gui.QPen, gui.QImage, gui.QPainterPath = QPainter, QColor, QPen, QImage, QPainterPath
@@ -497,6 +564,77 @@ FFMPEG_DEVICES = [None, "", "cpu", "off", "0", "auto", " AUTO ", "nvenc:1", "nve
                   "vaapi:/dev/dri/renderD128", "videotoolbox", "videotoolbox:0", "bogus"]
 
 
+def capture_center_image(name, kind, n, sr, fps, size, frames, image_size, view_state, sensitivity=1.0):
+    """Spectrum - Radial with a centre image (rt_widget.py:1060-1090): per frame the clip path, the arguments of
+    `img.scaled(out_w, out_h, IgnoreAspectRatio, SmoothTransformation)` and of `p.drawImage(dx, dy, ...)`."""
+    from export.exporter import QPainterOffscreenRenderer
+    audio = _track(kind, n, sr, 2)
+    path = f"mem://ci_{name}"
+    _AUDIO[path] = (audio, sr)
+    w, h = size
+    vs = dict(view_state, center_image_path=f"/nonexistent/memimg_{image_size[0]}x{image_size[1]}.png")
+    r = QPainterOffscreenRenderer(w, h, "Spectrum - Radial", (0.2, 0.8, 1.0), sensitivity, fps, path, **vs)
+    assert r._view.center_image is not None and not r._view.center_image.isNull()
+    total = int(np.ceil(r.duration * fps))
+    out = dict(audio=audio, sample_rate=sr, fps=fps, frames=np.asarray(frames), size=np.asarray(size),
+               image_size=np.asarray(image_size), sensitivity=sensitivity,
+               view_state_json=np.asarray(__import__("json").dumps(view_state)))
+    keep = set(int(f) for f in frames)
+    for i in range(total):
+        s, spec = r._read_frame(i / fps)
+        img = r._view.render_frame_to_qimage(w, h, s, spec)
+        if i not in keep:
+            continue
+        calls = img.calls
+        di = [c for c in calls if c[0] == "drawImage"]
+        assert len(di) == 1 and not any(c[0] == "fillPath" for c in calls)
+        _, dx, dy, out_size, sf = di[0]
+        assert sf[0] == tuple(image_size) and sf[1] == out_size and sf[2] == _Qt.IgnoreAspectRatio and sf[3] == 1
+        names = [c[0] for c in calls]
+        k = names.index("setClipPath")
+        assert ("setRenderHint", QPainter.Antialiasing, True) in calls[:k] and names.index("drawImage") > k
+        key = f"f{i}"
+        out[key + "_clip"] = _path_xy(calls[k][1])
+        out[key + "_placement"] = np.asarray([out_size[0], out_size[1], dx, dy], np.int64)
+        out[key + "_phase"] = np.float64(r._view._phase)
+        out[key + "_energy"] = np.float64(np.clip(np.mean(np.abs(s)) * r._view.waveform_sensitivity, 0.0, 1.0))
+    np.savez_compressed(os.path.join(HERE, f"images_center_{name}.npz"), **out)
+    print(f"images_center_{name}: {len(out)} arrays")
+
+
+def capture_background(name, cases):
+    """`_draw_background` (rt_widget.py:505-575) for (frame size, image size, scale mode, offsets, dim) cases: every
+    `drawImage(x, y, image)` with the size of what is drawn and the `scaled()` arguments behind it, and the dim fill."""
+    from export.exporter import QPainterOffscreenRenderer
+    audio = _track("pink", 2000, 48000, 2)
+    path = f"mem://bg_{name}"
+    _AUDIO[path] = (audio, 48000)
+    rows, draws = [], []
+    for (w, h, iw, ih, mode, ox, oy, dim) in cases:
+        vs = dict(background_path=f"/nonexistent/memimg_{iw}x{ih}.png", background_scale_mode=mode,
+                  background_offset_x=ox, background_offset_y=oy, background_dim_percent=dim)
+        r = QPainterOffscreenRenderer(w, h, "Spectrum - Linear", (0.2, 0.8, 1.0), 1.0, 60, path, **vs)
+        s, spec = r._read_frame(0.0)
+        calls = r._view.render_frame_to_qimage(w, h, s, spec).calls
+        names = [c[0] for c in calls]
+        assert names[0] == "fillRect" and calls[0][2][:3] == (13, 13, 18)
+        first_pen = names.index("setPen")
+        di = [c for c in calls[:first_pen] if c[0] == "drawImage"]
+        dims = [c for c in calls[1:first_pen] if c[0] == "fillRect"]
+        assert len(dims) <= 1 and all(c[1] == (0, 0, w, h) and c[2][:3] == (0, 0, 0) for c in dims)
+        dim_alpha = dims[0][2][3] if dims else 0
+        for c in di:
+            sf = c[4]
+            draws.append([len(rows), c[1], c[2], c[3][0], c[3][1], -1 if sf is None else sf[2]])
+            if sf is not None:
+                assert sf[0] == (iw, ih) and sf[1] == (w, h) and sf[3] == 1
+        rows.append([w, h, iw, ih, ox, oy, dim, dim_alpha, len(di)])
+    np.savez_compressed(os.path.join(HERE, f"images_background_{name}.npz"),
+                        cases=np.asarray(rows, np.int64), modes=np.asarray([c[4] for c in cases]),
+                        draws=np.asarray(draws, np.int64))
+    print(f"images_background_{name}: {len(rows)} cases, {len(draws)} drawImage calls")
+
+
 class _FakeDri:
     """Stands in for pathlib.Path inside the exporter module: /dev/dri with two render nodes."""
     def __init__(self, p): self.p = str(p)
@@ -561,6 +699,26 @@ def main():
                      dict(glow_enabled=True, glow_color="#FFFF4060", glow_radius=9, glow_strength=100,
                           shadow_enabled=True, radial_fill_enabled=True, radial_fill_threshold=0.0), [0, 3],
                      sensitivity=2.5)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "images":         # adds the images_* fixtures only
+        _install_stand_ins()
+        sys.path.insert(0, REF)
+        capture_center_image("static", "pink", 6000, 48000, 60, (1280, 720), [0, 1, 4, 7], (640, 480), {})
+        capture_center_image("motion_wavy", "pink", 12000, 48000, 60, (1920, 1080), [0, 1, 3, 8, 14], (333, 517),
+                             dict(center_motion=70, center_image_zoom=140, edge_waviness=60, feather_audio_enabled=True,
+                                  feather_audio_amount=80), sensitivity=1.8)
+        capture_center_image("small_zoomed_out", "sweep", 11025, 44100, 30, (1000, 562), [0, 2, 5], (4000, 3000),
+                             dict(center_motion=100, center_image_zoom=50, radial_rotation_deg=25.0))
+        cases = []
+        for (w, h) in ((1280, 720), (1000, 562), (3840, 2160)):
+            for (iw, ih) in ((640, 480), (4000, 1500), (300, 900), (1280, 720)):
+                for mode in ("fill", "fit", "stretch", "center", "tile"):
+                    cases.append((w, h, iw, ih, mode, 0, 0, 0))
+        cases += [(1280, 720, 640, 480, "fill", 25, -40, 35), (1280, 720, 640, 480, "fit", -300, 10, 100),
+                  (1280, 720, 500, 300, "tile", 37, 21, 50), (1280, 720, 500, 300, "tile", -37, -21, 1),
+                  (1920, 1080, 800, 600, "center", 111, -77, 99), (1920, 1080, 7, 5, "FILL", 0, 0, 150),
+                  (1920, 1080, 800, 600, "unknown-mode", 3, 4, -5)]
+        capture_background("plans", cases)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "multichannel":   # adds the analysis_*ch* fixtures only
         _install_stand_ins()

@@ -148,8 +148,14 @@ def test_full_track_render_checksums_and_samples(eng, track4min, mode, size):
             want = R.render_frame(mode, _np(smp[f]), _np(ls[f]), float(energy[f]), pen[f], W, H)
             palette = {tuple(R.BG), tuple(pen[f])}
         assert np.array_equal(got, want), (mode, f)
-        cols = {tuple(c) for c in np.unique(got.reshape(-1, 3), axis=0)}
-        assert cols <= palette and tuple(R.BG) in cols
+        px = got.reshape(-1, 3)
+        known = np.zeros(px.shape[0], bool)
+        for c in palette:
+            known |= (px == np.asarray(c, np.uint8)).all(axis=1)
+        assert (px == np.asarray(R.BG, np.uint8)).all(axis=1).any()
+        # only the antialiased rim of the centre disc (about one pixel wide) holds blended colours
+        rim = int(4 * 2 * np.pi * 0.22 * min(W, H)) if radial else 0
+        assert int((~known).sum()) <= rim, (mode, f, int((~known).sum()))
 
 
 def test_full_track_linear_waveform_shadow_properties(eng, track4min):

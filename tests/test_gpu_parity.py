@@ -423,7 +423,14 @@ def test_worker_end_to_end_raw_stream(eng, tmp_path, capsys):
     want = _np(FramePipeline(eng, track, "Waveform - Circular", W, H,
                              glow=GlowConfig.from_view_state(vs)).render_device()).tobytes()
     assert raw.read_bytes() == want
-    cfg["view_state"] = {"hip_device": 0, "background_path": "bg.png"}
+    # a background file that cannot be read is no background (`QImage(path).isNull()`, rt_widget.py:508-509): same bytes
+    cfg["view_state"] = dict(vs, background_path=str(tmp_path / "missing.png"))
+    cfgp.write_text(json.dumps(cfg))
+    assert worker.main(["worker.py", str(cfgp)]) == 0
+    capsys.readouterr()
+    assert raw.read_bytes() == want
+    # an export that cannot be rendered ends with the error message and exit status 1 (worker.py:77-79)
+    cfg["width"] = 32
     cfgp.write_text(json.dumps(cfg))
     assert worker.main(["worker.py", str(cfgp)]) == 1
     assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["type"] == "error"
@@ -847,7 +854,7 @@ def test_shadow_decoration_raster_bit_exact(eng, mode, vs):
         if env is not None:
             R.blend_solid(want, R.unpack_mask(R.stroke_mask_closed(env[f], W, H, sh.half_width, dx, dy, False), W),
                           (0, 0, 0), sh.alpha)
-            want[R.unpack_mask(R.polygon_mask(env[f], W, H), W)] = np.asarray(R.DISC_RGB, np.uint8)
+            R.draw_center_disc(want, env[f], W, H)
         if rings_all is not None:
             for rv, a in zip(rings_all[f], alphas):
                 R.blend_solid(want, R.unpack_mask(R.polygon_mask(rv, W, H), W), R.BG, a)
@@ -909,7 +916,7 @@ def test_glow_decoration_raster_bit_exact(eng, mode, vs, size):
             if sh.active:
                 R.blend_solid(want, R.unpack_mask(R.stroke_mask_closed(env[f], W, H, sh.half_width, dx, dy, False), W),
                               (0, 0, 0), sh.alpha)
-            want[R.unpack_mask(R.polygon_mask(env[f], W, H), W)] = np.asarray(R.DISC_RGB, np.uint8)
+            R.draw_center_disc(want, env[f], W, H)
         if rings_all is not None:
             for rv, a in zip(rings_all[f], alphas):
                 R.blend_solid(want, R.unpack_mask(R.polygon_mask(rv, W, H), W), R.BG, a)

@@ -2,12 +2,16 @@
 
 CPU-only.  Analysis outputs must be BIT-EXACT (same numpy ops, same order); draw lists must be exact.
 """
+import os
+
 import numpy as np
 import pytest
 
 from conftest import golden_analysis_names, load_golden
 from oracle import analysis_ref as A
 from oracle import raster_ref as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _audio(g):
@@ -365,3 +369,81 @@ def test_add_solid_saturates():
     R.add_solid(fr, np.array([[True, True]]), (255, 64, 96), 97)
     # div255(255*97) = 97, div255(64*97) = 24, div255(96*97) = 37
     assert fr.tolist() == [[[110, 37, 55], [255, 124, 37]]]
+
+
+# ----------------------------------------------------------------------------- centre image / background image draw calls
+@pytest.mark.parametrize("name", ["static", "motion_wavy", "small_zoomed_out"])
+def test_center_image_placement_vs_reference_draw_calls(name):
+    """`p.drawImage(dx, dy, img.scaled(out_w, out_h, ...))` as the reference issued it (rt_widget.py:1065-1090), from the
+    clip path, energy and phase of the same frame."""
+    import json
+    g = np.load(os.path.join(GOLDEN, f"images_center_{name}.npz"))
+    vs = json.loads(str(g["view_state_json"]))
+    iw, ih = (int(v) for v in g["image_size"])
+    zoom = max(50, min(250, int(vs.get("center_image_zoom", 100))))
+    cm = max(0, min(100, int(vs.get("center_motion", 0))))
+    for f in g["frames"]:
+        want = tuple(int(v) for v in g[f"f{f}_placement"])
+        got = R.center_image_placement(g[f"f{f}_clip"], iw, ih, zoom, cm, float(g[f"f{f}_energy"]), float(g[f"f{f}_phase"]))
+        assert got == want, (name, int(f), got, want)
+
+
+def test_background_plan_vs_reference_draw_calls():
+    """Where `_draw_bg_image` puts the background (rt_widget.py:519-545): size of the scaled image, draw position, tiling
+    and dim alpha of the oracle and of the host-side plan against the reference's own drawImage / fillRect calls."""
+    from aurora_amd.images import BackgroundConfig
+    g = np.load(os.path.join(GOLDEN, "images_background_plans.npz"))
+    cases, modes, draws = g["cases"], g["modes"], g["draws"]
+    for k, (w, h, iw, ih, ox, oy, dim, dim_alpha, ndraw) in enumerate(cases):
+        w, h, iw, ih, ox, oy, dim, dim_alpha, ndraw = (int(v) for v in (w, h, iw, ih, ox, oy, dim, dim_alpha, ndraw))
+        mode = str(modes[k])
+        mine = draws[draws[:, 0] == k]
+        assert len(mine) == ndraw
+        for plan in (R.background_plan(iw, ih, w, h, mode, (ox, oy), dim),
+                     BackgroundConfig("x", mode, ox, oy, dim).plan(iw, ih, w, h)):
+            sw, sh, tile, x, y, da = plan
+            assert da == dim_alpha, (k, mode, da, dim_alpha)
+            if tile:
+                want = sorted((tx + ox, ty + oy) for ty in range(0, h, ih) for tx in range(0, w, iw))
+                assert sorted((int(d[1]), int(d[2])) for d in mine) == want
+                assert all((int(d[3]), int(d[4])) == (iw, ih) and int(d[5]) == -1 for d in mine)
+            else:
+                assert ndraw == 1
+                d = mine[0]
+                assert (int(d[1]), int(d[2]), int(d[3]), int(d[4])) == (x, y, sw, sh), (k, mode, plan, d)
+                # aspect mode handed to scaled(): 1 Keep (fit), 0 Ignore (stretch), 2 KeepByExpanding; -1: not scaled
+                want_aspect = {"center": -1, "fit": 1, "stretch": 0}.get(mode.lower(), 2)
+                assert int(d[5]) == want_aspect
+
+
+def test_aa_coverage_known_answers():
+    """coverage_aa on shapes whose exact coverage is known: pixel-aligned and fractional rectangles, orientation, and the
+    area of a many-sided polygon (sum of coverages / 255 within the 1/256 quantisation of its rim)."""
+    V = np.array([[10.5, 10.25], [20.5, 10.25], [20.5, 15.0], [10.5, 15.0]])
+    c = R.coverage_aa(V, 32, 24)
+    assert c[10, 10] == 96 and c[10, 11] == 192 and c[11, 10] == 128 and c[11, 11] == 255 and c[15, 11] == 0
+    assert np.array_equal(c, R.coverage_aa(V[::-1], 32, 24))
+    assert c.sum() == 96 * 2 + 192 * 9 + 128 * 8 + 255 * 36
+    n = 360
+    a = 2 * np.pi * np.arange(n) / n
+    P = np.stack([50.3 + 20.25 * np.cos(a), 40.7 + 20.25 * np.sin(a)], axis=1)
+    cov = R.coverage_aa(P, 100, 80)
+    area = 0.5 * abs(np.sum(P[:, 0] * np.roll(P[:, 1], -1) - np.roll(P[:, 0], -1) * P[:, 1]))
+    assert abs(cov.astype(np.int64).sum() / 255.0 - area) < 1.0
+    inside = R.unpack_mask(R.polygon_mask(P, 100, 80), 100)
+    assert ((cov == 255) <= inside).all() and (inside <= (cov > 0)).all()
+    # a polygon that leaves the frame on the left still fills the pixels to the right of its edge
+    Q = np.array([[-5.0, 2.0], [6.0, 2.0], [6.0, 6.0], [-5.0, 6.0]])
+    cq = R.coverage_aa(Q, 16, 8)
+    assert (cq[2:6, 0:6] == 255).all() and cq[2:6, 6:].sum() == 0 and cq[:2].sum() == 0
+
+
+def test_smooth_scale_known_answers():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (6, 8, 4), dtype=np.uint8)
+    assert np.array_equal(R.smooth_scale(img, 8, 6), img)                      # same size: every weight is zero
+    flat = np.full((5, 7, 4), 200, np.uint8)
+    for (dw, dh) in ((3, 2), (20, 11), (3, 11), (20, 2)):                      # all four axis combinations
+        assert (R.smooth_scale(flat, dw, dh) == 200).all(), (dw, dh)
+    half = R.smooth_scale(img, 4, 3)                                           # exact 2x2 box average, truncated
+    assert np.array_equal(half[0, 0], img[0:2, 0:2].reshape(-1, 4).astype(np.int64).sum(0) // 4)

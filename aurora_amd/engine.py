@@ -378,6 +378,7 @@ class HipExportEngine:
         self.lib = self.ctx.lib
         self._tables = {}
         self._work = None
+        self._glow_work = None
         self._base = None
 
     # ------------------------------------------------------------------ plumbing
@@ -709,9 +710,9 @@ class HipExportEngine:
 
     def apply_glow(self, glow: GlowConfig, verts, sc: Scan, first: int, count: int, excl_a, excl_b, excl_b_static,
                    frames):
-        """`_draw_glow_offscreen` of the closed path ``verts`` float64 [count, n, 2]: one RoundJoin stroke plane per
-        layer, added (CompositionMode_Plus) in the layer's premultiplied colour wherever the planes ``excl_a`` /
-        ``excl_b`` (stroke and disc, painted afterwards with opaque colours) have no bit (in place)."""
+        """`_draw_glow_offscreen` of the closed path ``verts`` float64 [count, n, 2]: every layer's antialiased RoundJoin
+        stroke from one distance pass, added (CompositionMode_Plus) in the layer's premultiplied colour wherever the
+        planes ``excl_a`` / ``excl_b`` (stroke and disc, painted afterwards with opaque colours) have no bit (in place)."""
         torch = self.torch
         H, W = int(frames.shape[1]), int(frames.shape[2])
         W32 = (W + 31) // 32
@@ -725,12 +726,15 @@ class HipExportEngine:
             cache = (key, torch.from_numpy(glow.layer_premultiplied(sc.energy.cpu().numpy())).to(self.device))
             sc._glow_pm = cache
         pm = cache[1][first:first + count]
-        planes = self.empty((K, count, H, W32), torch.int32)
-        for k, (width, _) in enumerate(table):
-            _lib.check(self.lib.aur_mask_stroke_path(h, _ptr(verts), int(verts.shape[1]), count, W, H, width / 2.0,
-                                                     0.0, 0.0, 1, 1, _ptr(planes[k]), st), "aur_mask_stroke_path")
-        _lib.check(self.lib.aur_add_planes(h, _ptr(planes), K, _ptr(pm), _ptr(excl_a), _ptr(excl_b),
-                                           int(bool(excl_b_static)), count, W, H, _ptr(frames), st), "aur_add_planes")
+        nv = int(verts.shape[1])
+        need = C.c_size_t(0)
+        _lib.check(self.lib.aur_glow_work_bytes(count, nv, C.byref(need)), "aur_glow_work_bytes")
+        if self._glow_work is None or self._glow_work.numel() < need.value:
+            self._glow_work = self.empty((need.value,), torch.uint8)
+        hw = (C.c_double * K)(*[width / 2.0 for width, _ in table])
+        _lib.check(self.lib.aur_glow_path(h, _ptr(verts), nv, count, W, H, K, hw, _ptr(pm), _ptr(excl_a), _ptr(excl_b),
+                                          int(bool(excl_b_static)), _ptr(self._glow_work), self._glow_work.numel(),
+                                          _ptr(frames), st), "aur_glow_path")
         return frames
 
     # QColor(13, 13, 18) with alpha max(10, 70 - 10 k), k = 1..6 (rt_widget.py:1099, :1116)

@@ -321,6 +321,19 @@ int aur_add_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t*
 int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, const uint32_t* d_disc_plane, int disc_static,
                       const uint8_t* d_pen_rgb /*[F,4]*/, int n_frames, int W, int H, uint8_t* d_frames, void* stream);
 
+/* Glow decoration of a closed path (`_draw_glow_path` -> `_draw_glow_offscreen`, rt_widget.py:598-616, :634-653): K
+ * antialiased RoundCap / RoundJoin strokes of the same path with half pen widths h_half_widths[K] (HOST array, paint
+ * order), CompositionMode_Plus in the per-frame premultiplied layer colours d_pm_rgb uint8 [F][K][4], in place on
+ * d_frames, wherever neither d_excl_a [F][H][ceil(W/32)] nor d_excl_b ([F] or one static plane) has a bit (what the
+ * reference paints afterwards with opaque colours; either may be NULL).  One distance pass serves all layers: coverage
+ * of a layer = area of the pixel within half its pen width of the path, rim taken as straight across the pixel.
+ * d_verts float64 [F][n_vertices][2], n_vertices <= 4096; d_work: aur_glow_work_bytes(...) bytes, 256-byte aligned. */
+int aur_glow_work_bytes(int n_frames, int n_vertices, size_t* out_bytes);
+int aur_glow_path(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H, int K,
+                  const double* h_half_widths, const uint8_t* d_pm_rgb, const uint32_t* d_excl_a,
+                  const uint32_t* d_excl_b, int excl_b_static, void* d_work, size_t work_bytes, uint8_t* d_frames,
+                  void* stream);
+
 /* ---- antialiased centre disc, centre image, background image ---------------------------------- */
 
 /* What fills the centre disc of "Spectrum - Radial" (widgets/rt_widget.py:1060-1094).

@@ -512,9 +512,8 @@ def render_wave_circular_frame(path_verts, pen_rgb, w, h, bg=BG):
 # ----------------------------------------------------------------------------- glow decoration
 # `_draw_glow_path` -> `_draw_glow_offscreen` (widgets/rt_widget.py:598-616, :634-653; the export always runs with
 # _offscreen_paint, export/exporter.py:118): after fill and path shadow, before the path's own stroke, the closed path is
-# stroked once per layer with a RoundCap / RoundJoin pen, CompositionMode_Plus.  Coverage here is aliased like the rest of
-# this rasteriser (pixel centre within half the pen width of the polyline = stroke_mask_closed(round_join=True)); the
-# reference turns antialiasing on for these strokes, which is NOT reproduced (Qt coverage is parity-unpinned anyway).
+# stroked once per layer with an antialiased RoundCap / RoundJoin pen, CompositionMode_Plus (round_stroke_coverage below;
+# Qt coverage is parity-unpinned).
 # Pen colours, widths, composition mode and call order are pinned by tests/golden/glow_*.npz.
 
 def qcolor_alpha_f(alpha: int) -> float:
@@ -554,13 +553,109 @@ def add_solid(frame, mask_bool, rgb, alpha):
     frame[mask_bool] = np.minimum(d + pm, 255).astype(np.uint8)
 
 
+# Antialiased round stroke (`setRenderHint(Antialiasing)`, RoundCap / RoundJoin pen: rt_widget.py:637, :649-650).  The
+# stroked shape is every point within half the pen width of the path; Qt fills it through its gray raster.  Qt's stroker
+# and rasteriser are not in the reference tree (**parity unpinned**); the rule here, mirrored bit for bit by
+# csrc/glow.hip, is the area a pixel shares with that shape when its rim is taken as straight across the pixel:
+#   d  = distance from the pixel centre to the nearest point q of the path, n = (centre - q) / d,
+#   s  = half_width - d  (signed depth of the centre inside the shape),
+#   coverage = area of the unit square on the inner side of the line at depth s with normal n, in 1/256 steps (255 max).
+# All float64, operation order as written (the kernels are built with contraction off).
+
+GLOW_REACH = 0.7072          # beyond this depth a pixel is entirely inside / outside (half diagonal of a pixel)
+
+
+def path_distance_field(verts, w, h, reach):
+    """(d2, qx, qy) float64 [h, w]: squared distance of every pixel centre to the nearest point of the closed polyline
+    ``verts`` and that point; exact wherever the distance is at most ``reach`` (inf / 0 where nothing is that near).
+    Ties go to the segment with the lowest index."""
+    V = np.asarray(verts, dtype=np.float64)
+    n = V.shape[0]
+    d2 = np.full((h, w), np.inf)
+    qx = np.zeros((h, w))
+    qy = np.zeros((h, w))
+    for i in range(n):
+        ax, ay = float(V[i, 0]), float(V[i, 1])
+        bx, by = float(V[(i + 1) % n, 0]), float(V[(i + 1) % n, 1])
+        if not (ax == ax and ay == ay and bx == bx and by == by):
+            continue
+        ex, ey = bx - ax, by - ay
+        l2 = ex * ex + ey * ey
+        inv = 1.0 / l2 if l2 > 0.0 else 0.0
+        x0 = max(0, int(math.floor(min(ax, bx) - reach - 1.0)))
+        x1 = min(w, int(math.ceil(max(ax, bx) + reach + 1.0)) + 1)
+        y0 = max(0, int(math.floor(min(ay, by) - reach - 1.0)))
+        y1 = min(h, int(math.ceil(max(ay, by) + reach + 1.0)) + 1)
+        if x1 <= x0 or y1 <= y0:
+            continue
+        px = np.arange(x0, x1, dtype=np.float64)[None, :] + 0.5
+        py = np.arange(y0, y1, dtype=np.float64)[:, None] + 0.5
+        t = ((px - ax) * ex + (py - ay) * ey) * inv
+        cx = np.where(t <= 0.0, ax, np.where(t >= 1.0, ax + ex, ax + t * ex))
+        cy = np.where(t <= 0.0, ay, np.where(t >= 1.0, ay + ey, ay + t * ey))
+        dd = (px - cx) * (px - cx) + (py - cy) * (py - cy)
+        sl = (slice(y0, y1), slice(x0, x1))
+        better = dd < d2[sl]
+        d2[sl] = np.where(better, dd, d2[sl])
+        qx[sl] = np.where(better, cx, qx[sl])
+        qy[sl] = np.where(better, cy, qy[sl])
+    return d2, qx, qy
+
+
+def round_stroke_coverage(d2, qx, qy, half_width):
+    """uint8 [h, w] coverage of the round stroke of half width ``half_width`` from a distance field."""
+    h, w = d2.shape
+    px = np.arange(w, dtype=np.float64)[None, :] + 0.5
+    py = np.arange(h, dtype=np.float64)[:, None] + 0.5
+    with np.errstate(invalid="ignore", divide="ignore"):
+        d = np.sqrt(d2)
+        s = half_width - d
+        nx = np.abs((px - qx) / d)
+        ny = np.abs((py - qy) / d)
+        a = np.maximum(nx, ny)
+        b = np.minimum(nx, ny)
+        u = s + (a + b) / 2.0
+        f_lo = (u * u) / ((2.0 * a) * b)
+        f_mid = (u - b / 2.0) / a
+        r = (a + b) - u
+        f_hi = 1.0 - (r * r) / ((2.0 * a) * b)
+        f = np.where(u <= 0.0, 0.0, np.where(u >= a + b, 1.0, np.where(u < b, f_lo, np.where(u <= a, f_mid, f_hi))))
+        c = np.floor(f * 256.0)
+    c = np.where(np.isfinite(c), c, 0.0)
+    c = np.minimum(np.maximum(c, 0.0), 255.0)
+    c = np.where(s >= GLOW_REACH, 255.0, np.where(s <= -GLOW_REACH, 0.0, c))
+    c = np.where(np.isfinite(d2), c, 0.0)
+    return c.astype(np.uint8)
+
+
+def plus_cov(frame, pm_rgb, cov):
+    """CompositionMode_Plus of the premultiplied colour with a per-pixel coverage, in place (Qt comp_func_solid_Plus with
+    const_alpha = coverage): r = min(255, d + s); d' = INTERPOLATE_PIXEL_255(r, cov, d, 255 - cov)."""
+    d = frame.astype(np.uint32)
+    c = cov.astype(np.uint32)[..., None]
+    r = np.minimum(d + np.asarray(pm_rgb, dtype=np.uint32), 255)
+    v = r * c + d * (255 - c)
+    out = (v + (v >> 8) + 0x80) >> 8
+    m = cov > 0
+    frame[m] = out[m].astype(np.uint8)
+    return frame
+
+
 def apply_glow(frame, path_verts, energy, keep_bool, w, h, rgba=(0xA0, 0xFF, 0xFF, 0x80), radius=22, strength=0.8,
                layers=8):
     """Glow of the closed path on ``frame`` (in place), restricted to the pixels ``keep_bool`` (those that neither the
-    stroke nor the disc, painted afterwards with opaque colours, cover)."""
-    for width, alpha in glow_pens(energy, rgba, radius, strength, layers):
-        m = unpack_mask(stroke_mask_closed(path_verts, w, h, half_width=width / 2.0, closed=True, round_join=True), w)
-        add_solid(frame, m & keep_bool, rgba[:3], alpha)
+    stroke nor the fully covered part of the disc, painted afterwards with opaque colours, cover): one antialiased
+    RoundCap / RoundJoin stroke per layer, CompositionMode_Plus, in the reference's layer order."""
+    pens = glow_pens(energy, rgba, radius, strength, layers)
+    if not pens:
+        return frame
+    reach = max(wd for wd, _ in pens) / 2.0 + 1.0
+    d2, qx, qy = path_distance_field(path_verts, w, h, reach)
+    for width, alpha in pens:
+        cov = round_stroke_coverage(d2, qx, qy, width / 2.0)
+        cov = np.where(keep_bool, cov, 0).astype(np.uint8)
+        pm = _div255(np.asarray(rgba[:3], dtype=np.uint32) * np.uint32(alpha))
+        plus_cov(frame, pm, cov)
     return frame
 
 

@@ -380,6 +380,7 @@ class HipExportEngine:
         self._work = None
         self._glow_work = None
         self._base = None
+        self.fill_events = None           # benchmarks set a list: (start, end, n_frames) HIP events around every plane fill
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):
@@ -918,8 +919,15 @@ class HipExportEngine:
         count = int(stroke.shape[0])
         if out is None:
             out = self.empty((count, H, W, 3), self.torch.uint8)
+        ev = self.fill_events
+        if ev is not None:
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(self.lib.aur_raster_planes(self.ctx.handle, _ptr(stroke), _ptr(disc), int(static), _ptr(pen_rgb),
                                               count, W, H, _ptr(out), self.stream()), "aur_raster_planes")
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1, count))
         return out
 
     def render_radial(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int = 0,

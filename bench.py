@@ -270,28 +270,28 @@ def main():
             while done < DF:
                 n = min(DB, DF - done)
                 s = i % slots
-                if radial is not None:
-                    planes = eng.radial_planes(prep, an, sc, W, H, done, n, planes_out=dev_spans[s][:, :n])
-                elif circular:
-                    planes = eng.wave_circular_planes(an, sc, W, H, done, n, planes_out=dev_spans[s][:, :n])
+                if planes_mode:
+                    # the whole frame as an export renders it (stroke plane, two-pass fill, decorations, antialiased
+                    # disc); the events the engine records bracket the plane fill (both passes) alone
+                    eng.fill_events = ev_f
+                    glow = GlowConfig(enabled=True) if args.glow else None
+                    if radial is not None:
+                        eng.render_radial(prep, an, sc, W, H, done, n, out=dev_frames[s][:n],
+                                          planes_out=dev_spans[s][:, :n], glow=glow)
+                    else:
+                        eng.render_wave_circular(an, sc, W, H, done, n, out=dev_frames[s][:n],
+                                                 planes_out=dev_spans[s][:, :n], glow=glow)
+                    eng.fill_events = None
                 else:
                     spans, _ = eng.spans(kind, an, sc, W, H, done, n, out=dev_spans[s][:n])
                     work = eng.summarize(spans, K, W, H)           # column summaries: their own small kernel
-                if ev_f is not None:                               # the events bracket the fill kernel alone
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                if planes_mode:
-                    eng.fill_planes(planes, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n])
-                else:
+                    if ev_f is not None:                           # the events bracket the fill kernel alone
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
                     eng.fill(spans, K, sc.pen_rgb[done:done + n], W, H, out=dev_frames[s][:n], work=work, work_ready=True)
-                if ev_f is not None:
-                    e1.record()
-                    ev_f.append((e0, e1, n))
-                if args.glow and planes_mode:
-                    verts = (eng.radial_path_vertices(prep, sc, W, H, done, n) if radial is not None
-                             else eng.wave_circular_vertices(an, sc, W, H, done, n))
-                    eng.apply_glow(GlowConfig(enabled=True), verts, sc, done, n, planes[0], planes[1], planes[2],
-                                   dev_frames[s][:n])
+                    if ev_f is not None:
+                        e1.record()
+                        ev_f.append((e0, e1, n))
                 if feather is not None:
                     eng.feather_blend(prep, an, sc, W, H, done, n, dev_frames[s][:n], with_disc=True)
                 done += n
@@ -343,7 +343,8 @@ def main():
 
     if roof is not None:
         lin = W % 16 == 0 and os.environ.get("AUR_FILL_MODE", "0") != "1"
-        roof["kernel"] = ("raster_fill_planes_kernel" if planes_mode else
+        roof["kernel"] = ("raster_fill_rows_kernel + raster_patch_planes_kernel (aur_raster_planes, both passes)"
+                          if planes_mode and W % 32 == 0 and lin else "raster_fill_planes_kernel" if planes_mode else
                           f"raster_fill_lin_kernel<{K}>" if lin else f"raster_fill16_kernel<{K}>")
     try:                                               # per-launch HBM bytes from separate --pmc passes, if collected
         with open(args.traffic_json) as fh:

@@ -253,3 +253,34 @@ def test_exporter_takes_image_keys(eng, tmp_path):
     g0 = r2.render_time(0.0)
     assert f0.shape == g0.shape == (192, 320, 3) and not np.array_equal(f0, g0)
     assert (g0[0, 0] == np.asarray(R.BG, np.uint8)).all() and not (f0[96, 0] == np.asarray(R.BG, np.uint8)).all()
+
+
+def test_wavy_disc_at_4k_matches_oracle(eng):
+    """The frame-dependent disc at 3840x2160 (box 2281 wide: the kernel's accumulators need more than 64 KB of LDS, the
+    path that raises the kernel's dynamic-LDS limit), a few frames against the oracle's coverage and blend; and the
+    frame-independent disc's rim list at the same size."""
+    import torch
+    from aurora_amd import synth
+    from aurora_amd.engine import RadialConfig
+    W, H = 3840, 2160
+    track = eng.upload_track(synth.pink(2400, 2, seed=15), 48000, 60)
+    an = eng.analyze(track)
+    sc = eng.scan(an)
+    for vs in (dict(edge_waviness=80, feather_audio_enabled=True, feather_audio_amount=100), {}):
+        cfg = RadialConfig.from_view_state(vs, 1.0)
+        prep = eng.radial_prepare(an, cfg)
+        n = 2
+        frames = torch.empty((n, H, W, 3), dtype=torch.uint8, device=eng.device)
+        frames[:] = torch.tensor(R.BG, dtype=torch.uint8, device=eng.device)
+        if cfg.disc_static:                                   # what pass 1 of the plane fill paints ahead of the rim
+            full = eng._static_disc(prep, an, sc, W, H, 0)["full"]
+            m = torch.from_numpy(R.unpack_mask(_np(full)[0].view(np.uint32), W)).to(eng.device)
+            frames[:, m] = torch.tensor(R.DISC_RGB, dtype=torch.uint8, device=eng.device)
+        eng.draw_disc(prep, an, sc, W, H, 0, n, frames)
+        got = _np(frames)
+        env = _np(eng._envelope(prep, an, sc, W, H, 0, n))
+        for f in range(n):
+            want = np.empty((H, W, 3), np.uint8)
+            want[:] = np.asarray(R.BG, np.uint8)
+            R.draw_center_disc(want, env[f], W, H)
+            assert np.array_equal(got[f], want), (vs, f, int(np.sum(got[f] != want)))

@@ -69,7 +69,104 @@ __global__ __launch_bounds__(256) void rgb24_to_yuv420p_kernel(const uint8_t* __
     *reinterpret_cast<uint16_t*>(dst + frame_px + frame_px / 4 + coff) = (uint16_t)v;
 }
 
+// ---- spans -> yuv420p directly (the span modes with the opt-in wire format) -------------------------------------------
+// A frame of the span modes holds two colours, background and pen, so its planar form follows from the spans alone: the
+// rgb24 frame (3 B written, 3 B read per pixel by the converter above) is never materialised; 1.5 B per pixel are written
+// once.  Same arithmetic as rgb24_to_yuv420p_kernel on the frame aur_raster_spans would have produced (bit-identical:
+// tests/test_gpu_parity.py::test_fused_yuv420p_fill).  One lane: 4 pixel columns, kPairs row pairs, spans in registers.
+constexpr int kPairs = 8;
+constexpr int kBgR = 13, kBgG = 13, kBgB = 18;                  // QColor(13, 13, 18), rt_widget.py:829
+
+template <int K>
+__global__ __launch_bounds__(256) void spans_to_yuv420p_kernel(const uint32_t* __restrict__ spans,
+                                                               const uint32_t* __restrict__ pen_rgb, int W, int H,
+                                                               uint8_t* __restrict__ yuv) {
+    const int f = blockIdx.z;
+    const int x4 = blockIdx.x * 256 + threadIdx.x;
+    if (x4 * 4 >= W) return;
+    const int pair0 = blockIdx.y * kPairs;
+    const uint32_t pen = pen_rgb[f];
+    const int pr = (int)(pen & 255u), pg = (int)((pen >> 8) & 255u), pb = (int)((pen >> 16) & 255u);
+    const uint32_t y_bg = (uint32_t)(((66 * kBgR + 129 * kBgG + 25 * kBgB + 128) >> 8) + 16);
+    const uint32_t y_pen = (uint32_t)(((66 * pr + 129 * pg + 25 * pb + 128) >> 8) + 16);
+    uint32_t lo[K][4], len[K][4];
+    const uint32_t* sp = spans + (long)f * K * W + 4 * x4;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint4 s = *reinterpret_cast<const uint4*>(sp + (long)k * W);
+        const uint32_t v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            lo[k][c] = v[c] & 0xffffu;
+            len[k][c] = (v[c] >> 16) - (v[c] & 0xffffu);
+        }
+    }
+    const size_t frame_px = (size_t)W * H;
+    uint8_t* dst = yuv + (size_t)f * (frame_px + frame_px / 2);
+    for (int pr2 = pair0; pr2 < pair0 + kPairs && 2 * pr2 < H; ++pr2) {
+        int cnt[2] = {0, 0};                                    // lit pixels of the lane's two 2x2 blocks
+        uint32_t yw[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t row = (uint32_t)(2 * pr2 + r);
+            uint32_t out = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bool lit = false;
+#pragma unroll
+                for (int k = 0; k < K; ++k) lit |= (row - lo[k][c]) < len[k][c];
+                out |= (lit ? y_pen : y_bg) << (8 * c);
+                cnt[c >> 1] += lit ? 1 : 0;
+            }
+            yw[r] = out;
+        }
+        uint32_t* ydst = reinterpret_cast<uint32_t*>(dst + (size_t)(2 * pr2) * W + 4 * x4);
+        ydst[0] = yw[0];
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ydst) + W) = yw[1];
+        uint32_t u = 0, v = 0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int n = cnt[b];
+            const int R = (n * pr + (4 - n) * kBgR + 2) >> 2, G = (n * pg + (4 - n) * kBgG + 2) >> 2;
+            const int B = (n * pb + (4 - n) * kBgB + 2) >> 2;
+            const int Cb = ((-38 * R - 74 * G + 112 * B + 128) >> 8) + 128;
+            const int Cr = ((112 * R - 94 * G - 18 * B + 128) >> 8) + 128;
+            u |= (uint32_t)Cb << (8 * b);
+            v |= (uint32_t)Cr << (8 * b);
+        }
+        const size_t coff = (size_t)pr2 * (W / 2) + 2 * x4;
+        *reinterpret_cast<uint16_t*>(dst + frame_px + coff) = (uint16_t)u;
+        *reinterpret_cast<uint16_t*>(dst + frame_px + frame_px / 4 + coff) = (uint16_t)v;
+    }
+}
+
 }  // namespace
+
+extern "C" int aur_raster_spans_yuv420p(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb,
+                                        int n_frames, int W, int H, uint8_t* d_yuv, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_raster_spans_yuv420p: n_frames %d outside [0, 65535]", n_frames);
+    AUR_REQUIRE(W >= 64 && W <= 16384 && H >= 16 && H <= 16384, "aur_raster_spans_yuv420p: frame size %dx%d unsupported",
+                W, H);
+    AUR_REQUIRE(W % 4 == 0 && H % 2 == 0, "aur_raster_spans_yuv420p: %dx%d: width must be a multiple of 4, height even",
+                W, H);
+    AUR_REQUIRE(K == 2 || K == 5, "aur_raster_spans_yuv420p: K=%d unsupported (2 or 5)", K);
+    AUR_REQUIRE(ctx->d_base == nullptr,
+                "aur_raster_spans_yuv420p: a background image is set; render rgb24 and convert (aur_rgb24_to_yuv420p)");
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_spans && d_pen_rgb && d_yuv, "aur_raster_spans_yuv420p: null device pointer");
+    AUR_REQUIRE(((uintptr_t)d_spans & 15u) == 0 && ((uintptr_t)d_pen_rgb & 3u) == 0 && ((uintptr_t)d_yuv & 3u) == 0,
+                "aur_raster_spans_yuv420p: misaligned device pointer");
+    const dim3 grid((W / 4 + 255) / 256, (H / 2 + kPairs - 1) / kPairs, n_frames);
+    const uint32_t* pen = reinterpret_cast<const uint32_t*>(d_pen_rgb);
+    if (K == 2)
+        hipLaunchKernelGGL(spans_to_yuv420p_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, d_spans, pen, W, H, d_yuv);
+    else
+        hipLaunchKernelGGL(spans_to_yuv420p_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, d_spans, pen, W, H, d_yuv);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
 
 extern "C" int aur_rgb24_to_yuv420p(aur_ctx* ctx, const uint8_t* d_rgb, int n_frames, int W, int H, uint8_t* d_yuv,
                                     void* stream) {

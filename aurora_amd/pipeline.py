@@ -204,6 +204,11 @@ class FramePipeline:
                           copy_stream=torch.cuda.Stream(device=eng.device))
         return self
 
+    def _fused_yuv_ok(self):
+        """yuv420p straight from the spans: span modes without a background image or a shadow layer."""
+        return (not self.planes and self.background is None and self.shadow is None
+                and self.W % 4 == 0 and self.H % 2 == 0)
+
     def close(self):
         """Frees the pinned ring (device tensors go back to torch's allocator with the object)."""
         if self._ring is not None:
@@ -271,9 +276,18 @@ class FramePipeline:
                 cur = torch.cuda.current_stream(eng.device)
                 if copied[slot] is not None:
                     cur.wait_event(copied[slot])           # device slot no longer being read by the copy engine
-                self._render(an, sc, done, n, out=dev_frames[slot][:n],
-                             scratch=dev_spans[slot][:, :n] if self.planes else dev_spans[slot][:n])
-                if yuv:
+                fused = yuv and self._fused_yuv_ok()
+                if fused:
+                    # span modes: the planar frame straight from the spans, no rgb24 frame in between
+                    spans, K = eng.spans(self.kind, an, sc, self.W, self.H, done, n, out=dev_spans[slot][:n])
+                    _lib.check(eng.lib.aur_raster_spans_yuv420p(
+                        eng.ctx.handle, C.c_void_p(spans.data_ptr()), K, C.c_void_p(sc.pen_rgb[done:done + n].data_ptr()),
+                        n, self.W, self.H, C.c_void_p(dev_wire[slot].data_ptr()), eng.stream()),
+                        "aur_raster_spans_yuv420p")
+                else:
+                    self._render(an, sc, done, n, out=dev_frames[slot][:n],
+                                 scratch=dev_spans[slot][:, :n] if self.planes else dev_spans[slot][:n])
+                if yuv and not fused:
                     _lib.check(eng.lib.aur_rgb24_to_yuv420p(
                         eng.ctx.handle, C.c_void_p(dev_frames[slot].data_ptr()), n, self.W, self.H,
                         C.c_void_p(dev_wire[slot].data_ptr()), eng.stream()), "aur_rgb24_to_yuv420p")

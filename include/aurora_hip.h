@@ -403,6 +403,13 @@ int aur_set_background(aur_ctx* ctx, const uint8_t* d_base, int W, int H);
  * W must be a multiple of 4 and H even. */
 int aur_rgb24_to_yuv420p(aur_ctx* ctx, const uint8_t* d_rgb, int n_frames, int W, int H, uint8_t* d_yuv, void* stream);
 
+/* The span modes straight into the yuv420p wire format: the frame aur_raster_spans would produce, converted as
+ * aur_rgb24_to_yuv420p converts it, without materialising it (a span-mode frame holds two colours, so its planes follow
+ * from the spans: 1.5 B per pixel written once instead of 3 written + 3 read + 1.5 written).  d_spans, K, d_pen_rgb as
+ * aur_raster_spans (d_spans 16-byte aligned); d_yuv uint8 [F][H * W * 3 / 2].  Not with a background image set. */
+int aur_raster_spans_yuv420p(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb, int n_frames, int W,
+                             int H, uint8_t* d_yuv, void* stream);
+
 /* ---- readback ---------------------------------------------------------------------------------- */
 
 /* Pinned host memory for the frame ring that feeds the FFmpeg pipe (replaces the arr.copy()/tobytes()

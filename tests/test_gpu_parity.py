@@ -665,6 +665,28 @@ def test_pipeline_yuv420p_stream(eng):
         FramePipeline(eng, track, "Spectrum - Linear", 322, H, wire_format="yuv420p")
 
 
+@pytest.mark.parametrize("mode", ["Spectrum - Linear", "Waveform - Linear", "Particles", "Spectrum - Radial"])
+@pytest.mark.parametrize("size", [(320, 192), (1284, 94), (3840, 64)])
+def test_fused_yuv420p_fill(eng, mode, size):
+    """yuv420p wire format of every mode == the conversion of the same pipeline's rgb24 frames: the span modes take
+    aur_raster_spans_yuv420p (no rgb24 frame in between), the others render rgb24 and convert."""
+    import io
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    from oracle import wire_ref as WR
+    W, H = size
+    track = eng.upload_track(synth.pink(5000, 2, seed=13), 48000, 60)
+    rgb = _np(FramePipeline(eng, track, mode, W, H).render_device())
+    buf = io.BytesIO()
+    pipe = FramePipeline(eng, track, mode, W, H, batch_frames=3, wire_format="yuv420p")
+    assert pipe._fused_yuv_ok() == (not mode.endswith("Radial"))
+    n = pipe.run(buf)
+    raw = np.frombuffer(buf.getvalue(), np.uint8).reshape(n, W * H * 3 // 2)
+    assert n == rgb.shape[0]
+    for f in range(n):
+        assert np.array_equal(raw[f], WR.rgb24_to_yuv420p(rgb[f])), (mode, size, f)
+
+
 # ------------------------------------------------------------------ feather rings
 
 def test_feather_ring_vertices_vs_reference(eng):

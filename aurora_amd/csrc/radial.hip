@@ -1179,6 +1179,30 @@ __global__ __launch_bounds__(256) void add_planes_kernel(const uint32_t* __restr
     }, W, x0, frames + (((size_t)f * H + row) * W + x0) * 3);
 }
 
+// CompositionMode_Multiply of a constant colour on the pixels of one plane (`_apply_fill` with radial_fill_blend =
+// "multiply" over a background image, rt_widget.py:859-862): Qt's multiply_op on premultiplied ARGB32 with an opaque
+// destination is d' = div255(s d + d (255 - a)) = div255(d (s + 255 - a)) per channel, s = div255(c a) <= a, so the
+// per-channel factor s + 255 - a (at most 255) comes from the host.  One lane per quarter word.
+template <bool VEC>
+__global__ __launch_bounds__(256) void multiply_plane_kernel(const uint32_t* __restrict__ plane, uint32_t fr, uint32_t fg,
+                                                             uint32_t fb, int W, int H, int W32,
+                                                             uint8_t* __restrict__ frames) {
+    const int f = blockIdx.y;
+    const int words = H * W32;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int word = id >> 2, q = id & 3;
+    if (word >= words) return;
+    const uint32_t m = (plane[(size_t)f * words + word] >> (8 * q)) & 0xffu;
+    if (m == 0u) return;
+    const int row = word / W32, w = word - row * W32;
+    const int x0 = w * 32 + q * 8;
+    quarter_rmw<VEC>(m, [&](int b, uint32_t& rb, uint32_t& g) {
+        const uint32_t r = div255(__umul24(rb & 0xffffu, fr)), bl = div255(__umul24(rb >> 16, fb));
+        rb = r | (bl << 16);
+        g = div255(__umul24(g, fg));
+    }, W, x0, frames + (((size_t)f * H + row) * W + x0) * 3);
+}
+
 template <int KT>
 static void launch_add(bool vec, dim3 grid, hipStream_t st, const uint32_t* planes, int K, size_t layer_stride,
                        const uint32_t* pm, const uint32_t* ea, const uint32_t* eb, int eb_static, int W, int H, int W32,
@@ -1297,6 +1321,32 @@ extern "C" int aur_add_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, con
     const int ebs = excl_b_static ? 1 : 0;
     if (K <= 8) launch_add<8>(vec, grid, st, d_planes, K, layer_stride, pm, d_excl_a, d_excl_b, ebs, W, H, W32, d_frames);
     else launch_add<kAddMaxK>(vec, grid, st, d_planes, K, layer_stride, pm, d_excl_a, d_excl_b, ebs, W, H, W32, d_frames);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+extern "C" int aur_multiply_plane(aur_ctx* ctx, const uint32_t* d_plane, const uint8_t* h_rgba, int n_frames, int W, int H,
+                                  uint8_t* d_frames, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_multiply_plane: n_frames %d outside [0, 65535]", n_frames);
+    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_multiply_plane: frame size %dx%d unsupported", W, H);
+    AUR_REQUIRE(h_rgba != nullptr, "aur_multiply_plane: null colour");
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_plane && d_frames, "aur_multiply_plane: null device pointer");
+    const uint32_t a = h_rgba[3];
+    uint32_t fac[3];
+    for (int ch = 0; ch < 3; ++ch) fac[ch] = div255((uint32_t)h_rgba[ch] * a) + 255u - a;
+    const int W32 = (W + 31) / 32;
+    const dim3 grid((4 * H * W32 + 255) / 256, n_frames);
+    const bool vec = W % 8 == 0 && ((uintptr_t)d_frames & 7u) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL(multiply_plane_kernel<true>, grid, dim3(256), 0, st, d_plane, fac[0], fac[1], fac[2], W, H, W32,
+                           d_frames);
+    else
+        hipLaunchKernelGGL(multiply_plane_kernel<false>, grid, dim3(256), 0, st, d_plane, fac[0], fac[1], fac[2], W, H, W32,
+                           d_frames);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

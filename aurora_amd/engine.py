@@ -687,7 +687,9 @@ class HipExportEngine:
                        "aur_add_planes")
             return frames
         if fill.blend == "multiply":
-            raise NotImplementedError("radial_fill_blend 'multiply' over a background image is not implemented")
+            _lib.check(self.lib.aur_multiply_plane(h, _ptr(plane), bytes(int(v) for v in fill.rgba), count, W, H,
+                                                   _ptr(frames), st), "aur_multiply_plane")
+            return frames
         return self.blend_planes(plane, bytes(int(v) for v in fill.rgba), frames)
 
     def apply_shadow(self, shadow: ShadowConfig, verts, closed: bool, excl_a, excl_b, excl_b_static, frames,

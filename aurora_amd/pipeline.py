@@ -107,8 +107,6 @@ class FramePipeline:
         self.glow = glow if (glow is not None and glow.active and self.planes) else None
         # background image (`_draw_background`, rt_widget.py:505-545): composed once, every frame starts from it
         self.background = background if (background is not None and background.active) else None
-        if (self.background is not None and self.fill is not None and self.fill.blend == "multiply"):
-            raise NotImplementedError("radial_fill_blend 'multiply' over a background image is not implemented")
         self._base = None
         self._base_done = False
         self._analysed = None

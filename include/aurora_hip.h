@@ -313,6 +313,13 @@ int aur_add_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t*
                    const uint32_t* d_excl_b, int excl_b_static, int n_frames, int W, int H, uint8_t* d_frames,
                    void* stream);
 
+/* CompositionMode_Multiply of the constant straight-alpha colour h_rgba[4] (HOST) on the pixels of d_plane uint32
+ * [n_frames, H, ceil(W/32)], in place: `_apply_fill` with radial_fill_blend = "multiply" (rt_widget.py:859-862) when the
+ * frame under it is a background image (over the plain background the result is one colour, composed by the caller).
+ * Qt's multiply_op with an opaque destination: d' = div255(d (div255(c a) + 255 - a)) per channel. */
+int aur_multiply_plane(aur_ctx* ctx, const uint32_t* d_plane, const uint8_t* h_rgba, int n_frames, int W, int H,
+                       uint8_t* d_frames, void* stream);
+
 /* RGB24 frames of "Spectrum - Radial" / "Waveform - Circular" (paint_frame, rt_widget.py:821-852): background
  * (13,13,18), stroke plane in the pen colour, disc plane in (30,30,40) on top (an all-zero static plane when the mode
  * has no disc).  Widths that are not a multiple of 16 take a per-pixel kernel.  disc_static != 0: d_disc_plane holds ONE

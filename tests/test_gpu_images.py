@@ -284,3 +284,43 @@ def test_wavy_disc_at_4k_matches_oracle(eng):
             want[:] = np.asarray(R.BG, np.uint8)
             R.draw_center_disc(want, env[f], W, H)
             assert np.array_equal(got[f], want), (vs, f, int(np.sum(got[f] != want)))
+
+
+@pytest.mark.parametrize("blend", ["normal", "add", "multiply"])
+def test_fill_decoration_over_a_background_image(eng, tmp_path, blend):
+    """`_apply_fill` (rt_widget.py:856-864) when the frame under it is a background image: the three composition modes
+    per pixel (over the plain background the result is one colour, composed on the host)."""
+    pytest.importorskip("PIL")
+    from aurora_amd import synth
+    from aurora_amd.engine import FillConfig
+    from aurora_amd.images import BackgroundConfig
+    from aurora_amd.pipeline import FramePipeline
+    from oracle import radial_ref as RR
+    W, H = 320, 192
+    rgba = _test_image(64, 48, 33)
+    path = str(tmp_path / "bg.png")
+    _write_png(path, rgba)
+    base = R.compose_background(R.premultiply(rgba), W, H, "stretch", (0, 0), 0)
+    fc = FillConfig(enabled=True, rgba=(200, 90, 40, 150), blend=blend, threshold=0.0)
+    track = eng.upload_track(synth.pink(2500, 2, seed=6), 48000, 60)
+    pipe = FramePipeline(eng, track, "Waveform - Circular", W, H, fill=fc,
+                         background=BackgroundConfig(path, "stretch", 0, 0, 0))
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    energy, pen, smp = _np(sc.energy), _np(sc.pen_rgb)[:, :3], _np(an.samples)
+    r, g, b, a = fc.rgba
+    for f in range(an.n_frames):
+        verts = RR.wave_circular_path(smp[f], float(energy[f]), W, H)
+        want = base.copy()
+        inside = R.unpack_mask(R.polygon_mask(verts, W, H), W)
+        d = want[inside].astype(np.uint32)
+        s = R.byte_mul(np.asarray([r, g, b], np.uint32), a)
+        if blend == "add":
+            out = np.minimum(d + s, 255)
+        elif blend == "multiply":
+            out = R.byte_mul(d, s + 255 - a)
+        else:
+            out = s + R.byte_mul(d, 255 - a)
+        want[inside] = out.astype(np.uint8)
+        want[R.unpack_mask(R.stroke_mask_closed(verts, W, H), W)] = pen[f]
+        assert np.array_equal(frames[f], want), (blend, f, int(np.sum(frames[f] != want)))

@@ -346,8 +346,18 @@ __device__ __forceinline__ void or_span(uint32_t* row, int c0, int c1, int W) {
     }
 }
 
-// Rows of a convex polygon (n <= 4 vertices) OR-ed into a bit plane.
-__device__ void raster_convex(uint32_t* plane, int W32, const double* px, const double* py, int n, int W, int H) {
+// Where the pixel runs of a stroke go: into a bit plane (atomicOr), or -- PaintSink further down -- straight into a frame.
+struct PlaneSink {
+    uint32_t* plane;
+    int W32, W;
+    __device__ __forceinline__ void span(long r, int c0, int c1) const { or_span(plane + r * W32, c0, c1, W); }
+};
+
+// Rows of a convex polygon (n <= 4 vertices) handed to the sink as pixel runs.
+// Rows r0 + lane_k, r0 + lane_k + lane_n, .. only: several lanes can share one primitive (the frame painter does).
+template <class Sink>
+__device__ void raster_convex(const Sink& sink, const double* px, const double* py, int n, int H, int lane_k = 0,
+                              int lane_n = 1) {
     double ymin = py[0], ymax = py[0];
     for (int i = 1; i < n; ++i) {
         ymin = fmin(ymin, py[i]);
@@ -359,7 +369,7 @@ __device__ void raster_convex(uint32_t* plane, int W32, const double* px, const 
     long r0 = (long)ceil(ymin - 0.5), r1 = (long)floor(ymax - 0.5) + 1;
     if (r0 < 0) r0 = 0;
     if (r1 > H) r1 = H;
-    for (long r = r0; r < r1; ++r) {
+    for (long r = r0 + lane_k; r < r1; r += lane_n) {
         const double yc = (double)r + 0.5;
         double xmin = kBig, xmax = -kBig;
         bool hit = false;
@@ -382,7 +392,7 @@ __device__ void raster_convex(uint32_t* plane, int W32, const double* px, const 
         if (!hit) continue;
         xmin = fmin(fmax(xmin, -kBig), kBig);
         xmax = fmin(fmax(xmax, -kBig), kBig);
-        or_span(plane + r * W32, (int)ceil(xmin - 0.5), (int)floor(xmax - 0.5) + 1, W);
+        sink.span(r, (int)ceil(xmin - 0.5), (int)floor(xmax - 0.5) + 1);
     }
 }
 
@@ -399,21 +409,17 @@ __device__ __forceinline__ bool seg_dir(const double* V, int n, int s, double& u
 // BevelJoin stroke of half-width hw (1 for the width-2 pen) of the closed polygon verts[f][nv][2] translated by (tx, ty):
 // thread t < nv draws segment t, thread nv + t the bevel at vertex t.  The plane must be zero on entry.  hw = 1 and
 // tx = ty = 0 reproduce the untranslated width-2 stroke bit for bit (x + 0 and n * 1 are exact).
-__global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* __restrict__ verts, int nv, int W, int H,
-                                                                 int W32, double hw, double tx, double ty,
-                                                                 int closed, int round_join,
-                                                                 uint32_t* __restrict__ planes) {
+template <class Sink>
+__device__ __forceinline__ void stroke_primitive(const double* __restrict__ V, int nv, int t, int H, double hw, double tx,
+                                                 double ty, int closed, int round_join, const Sink& sink, int lane_k = 0,
+                                                 int lane_n = 1) {
     // closed == 0: open polyline (the envelope path of `_draw_center_image_and_mask` has no closeSubpath): no segment
     // from the last vertex to the first, no join at either end, SquareCap = the end segments extended by hw.
-    const int f = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= 2 * nv) return;
     // round_join != 0 (RoundCap / RoundJoin pen): plain segment rectangles and a disc of radius hw at every vertex,
     // i.e. every pixel centre within hw of the polyline.
     if (!closed && t == nv - 1) return;
     if (!closed && !round_join && (t == nv || t == 2 * nv - 1)) return;
-    const double* V = verts + (long)f * nv * 2;
-    uint32_t* plane = planes + (long)f * H * W32;
     double px[4], py[4];
     if (t < nv) {
         double ux, uy;
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
         px[1] = bx + nx; py[1] = by + ny;
         px[2] = bx - nx; py[2] = by - ny;
         px[3] = ax - nx; py[3] = ay - ny;
-        raster_convex(plane, W32, px, py, 4, W, H);
+        raster_convex(sink, px, py, 4, H, lane_k, lane_n);
     } else {
         const int v = t - nv;
         if (round_join) {
@@ -443,13 +449,13 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
             long r0 = (long)ceil(yl - 0.5), r1 = (long)floor(yh - 0.5) + 1;
             if (r0 < 0) r0 = 0;
             if (r1 > H) r1 = H;
-            for (long r = r0; r < r1; ++r) {
+            for (long r = r0 + lane_k; r < r1; r += lane_n) {
                 const double dyc = ((double)r + 0.5) - vy;
                 const double c2 = hw * hw - dyc * dyc;
                 if (c2 < 0.0) continue;
                 const double c = sqrt(c2);
                 const double xl = fmin(fmax(vx - c, -kBig), kBig), xh = fmin(fmax(vx + c, -kBig), kBig);
-                or_span(plane + r * W32, (int)ceil(xl - 0.5), (int)floor(xh - 0.5) + 1, W);
+                sink.span(r, (int)ceil(xl - 0.5), (int)floor(xh - 0.5) + 1);
             }
             return;
         }
@@ -463,8 +469,17 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
         px[0] = vx; py[0] = vy;
         px[1] = vx + sg * (-uya) * hw; py[1] = vy + sg * uxa * hw;
         px[2] = vx + sg * (-uyb) * hw; py[2] = vy + sg * uxb * hw;
-        raster_convex(plane, W32, px, py, 3, W, H);
+        raster_convex(sink, px, py, 3, H, lane_k, lane_n);
     }
+}
+
+__global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* __restrict__ verts, int nv, int W, int H,
+                                                                 int W32, double hw, double tx, double ty,
+                                                                 int closed, int round_join,
+                                                                 uint32_t* __restrict__ planes) {
+    const int f = blockIdx.y;
+    const PlaneSink sink = {planes + (long)f * H * W32, W32, W};
+    stroke_primitive(verts + (long)f * nv * 2, nv, blockIdx.x * 256 + threadIdx.x, H, hw, tx, ty, closed, round_join, sink);
 }
 
 // Even-odd fill of the implicitly closed polygon verts[f][nv][2], sampled at pixel centres.  A pixel is inside iff an odd
@@ -704,6 +719,78 @@ __global__ __launch_bounds__(256) void disc_rows_kernel(const uint32_t* __restri
         uint32_t t = 0u;
         if (count > 0) t = (count == last - first + 1) ? ((uint32_t)first | ((uint32_t)(last + 1) << 16)) : kRowMulti;
         rows[(long)f * H + row] = t;
+    }
+}
+
+// Pen pixels straight into the frame (aur_raster_closed_path): what pass 2 would patch in from a stroke plane, without the
+// plane.  The disc is painted last in the reference, so a run leaves out the row's disc interval (or, in a row whose disc
+// is not one interval, every pixel whose disc bit is set).  All primitives paint the same colour: overlaps need no order.
+struct PaintSink {
+    uint8_t* frame;                  // this frame, uint8 [H][W][3]
+    const uint32_t* rows;            // this frame's disc row table
+    const uint32_t* disc;            // this frame's disc plane (only read in kRowMulti rows)
+    int W, W32;
+    uint32_t pen;
+    __device__ __forceinline__ void span(long r, int c0, int c1) const {
+        if (c0 < 0) c0 = 0;
+        if (c1 > W) c1 = W;
+        if (c1 <= c0) return;
+        const uint32_t t = rows[r];
+        const int x0 = (int)(t & 0xffffu), x1 = (int)(t >> 16);
+        uint8_t* p = frame + ((long)r * W + c0) * 3;
+        for (int c = c0; c < c1; ++c, p += 3) {
+            if (t == kRowMulti) {
+                if ((disc[r * W32 + (c >> 5)] >> (c & 31)) & 1u) continue;
+            } else if (c >= x0 && c < x1) {
+                continue;
+            }
+            p[0] = (uint8_t)pen;
+            p[1] = (uint8_t)(pen >> 8);
+            p[2] = (uint8_t)(pen >> 16);
+        }
+    }
+};
+
+constexpr int kPaintLanes = 8;
+__global__ __launch_bounds__(256) void paint_stroke_closed_kernel(const double* __restrict__ verts, int nv, int W, int H,
+                                                                  int W32, const uint32_t* __restrict__ rows,
+                                                                  const uint32_t* __restrict__ disc, int disc_static,
+                                                                  const uint32_t* __restrict__ pen_rgb,
+                                                                  uint8_t* __restrict__ frames) {
+    const int f = blockIdx.y;
+    const long fr = disc_static ? 0 : f;
+    const PaintSink sink = {frames + (long)f * H * W * 3, rows + fr * H, disc + fr * H * W32, W, W32,
+                            pen_rgb[f] & 0x00ffffffu};
+    // kPaintLanes lanes per primitive, each taking every kPaintLanes-th of its pixel rows: the walk over a primitive's rows
+    // is a chain of dependent float64 divisions, and one lane per primitive left the kernel latency-bound
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    stroke_primitive(verts + (long)f * nv * 2, nv, t / kPaintLanes, H, 1.0, 0.0, 0.0, 1, 0, sink, t % kPaintLanes,
+                     kPaintLanes);
+}
+
+// Disc pixels of the rows pass 1 could not describe by one interval (kRowMulti).  One lane per (frame, row): it returns at
+// once for every other row -- all rows of the discs an export produces, so the launch costs a few microseconds -- and walks
+// the row's plane words itself otherwise.
+__global__ __launch_bounds__(256) void paint_disc_multi_rows_kernel(const uint32_t* __restrict__ rows,
+                                                                    const uint32_t* __restrict__ disc, int disc_static,
+                                                                    int W, int H, int W32, int n_frames,
+                                                                    uint8_t* __restrict__ frames) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_frames * H) return;
+    const int f = i / H, row = i - f * H;
+    const long fr = disc_static ? 0 : f;
+    if (rows[fr * H + row] != kRowMulti) return;
+    const uint32_t* src = disc + (fr * H + row) * W32;
+    uint8_t* dst = frames + ((long)f * H + row) * (long)W * 3;
+    for (int w = 0; w < W32; ++w) {
+        uint32_t bits = src[w];
+        while (bits) {
+            const int x = 32 * w + __builtin_ctz(bits);
+            bits &= bits - 1u;
+            dst[3 * x] = (uint8_t)kDisc24;
+            dst[3 * x + 1] = (uint8_t)(kDisc24 >> 8);
+            dst[3 * x + 2] = (uint8_t)(kDisc24 >> 16);
+        }
     }
 }
 
@@ -1482,6 +1569,53 @@ extern "C" int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, c
     hipLaunchKernelGGL(raster_fill_planes_kernel, dim3((nchunks * ntiles + 3) / 4, n_frames), dim3(256), 0,
                        (hipStream_t)stream, d_stroke_plane, d_disc_plane, reinterpret_cast<const uint32_t*>(d_pen_rgb), W,
                        H, W32, nu4, nchunks, disc_static ? 1 : 0, reinterpret_cast<uint4*>(d_frames));
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+// A batch of closed-path frames without a stroke plane: pass 1 of aur_raster_planes, then the stroke painted straight into
+// the frames.  For renders that need no stroke plane afterwards (no fill / shadow / glow decoration).  Same frames as
+// aur_mask_stroke_closed + aur_raster_planes, bit for bit.
+extern "C" int aur_raster_closed_path(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
+                                      const uint32_t* d_disc_plane, int disc_static, const uint8_t* d_pen_rgb,
+                                      uint8_t* d_frames, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    if ((rc = check_plane_args("aur_raster_closed_path", n_frames, n_vertices, W, H))) return rc;
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_verts && d_disc_plane && d_pen_rgb && d_frames, "aur_raster_closed_path: null device pointer");
+    AUR_REQUIRE(((uintptr_t)d_pen_rgb & 3u) == 0, "aur_raster_closed_path: misaligned d_pen_rgb");
+    if ((rc = aur_check_background(ctx, "aur_raster_closed_path", W, H))) return rc;
+    const int W32 = (W + 31) / 32, nu4 = W * 3 / 16;
+    const long upf_l = (long)nu4 * H;
+    const int table_frames = disc_static ? 1 : n_frames;
+    const bool ok = W % 32 == 0 && ((uintptr_t)d_frames & 15u) == 0 && ctx->fill_mode != 1 && ctx->d_rows != nullptr &&
+                    upf_l >= 256 && upf_l < (1L << 26) && (long)n_frames * upf_l + 256 < (1L << 31) &&
+                    (size_t)table_frames * H * 4 <= (size_t)AUR_ROWS_BYTES;
+    if (!ok) {
+        aur_set_error("aur_raster_closed_path: %dx%d frames (or this batch) are outside the linear fill's shapes; use "
+                      "aur_mask_stroke_closed + aur_raster_planes", W, H);
+        return AUR_EUNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* rows = reinterpret_cast<uint32_t*>(ctx->d_rows);
+    hipLaunchKernelGGL(disc_rows_kernel, dim3((H + 3) / 4, table_frames), dim3(256), 0, st, d_disc_plane, H, W32, rows);
+    const int upf = (int)upf_l;
+    const int head = (int)(((uintptr_t)d_frames & 4095u) / 16u);
+    const unsigned total = (unsigned)n_frames * (unsigned)upf;
+    const unsigned gfill = (unsigned)(((unsigned long)total + (unsigned)head + 255u) / 256u);
+    const uint4* base = reinterpret_cast<const uint4*>(ctx->d_base);
+    if (base != nullptr)
+        hipLaunchKernelGGL(raster_fill_rows_kernel<true>, dim3(gfill), dim3(256), 0, st, rows, disc_static ? 1 : 0, H, nu4,
+                           upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, base, reinterpret_cast<uint4*>(d_frames));
+    else
+        hipLaunchKernelGGL(raster_fill_rows_kernel<false>, dim3(gfill), dim3(256), 0, st, rows, disc_static ? 1 : 0, H, nu4,
+                           upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, base, reinterpret_cast<uint4*>(d_frames));
+    hipLaunchKernelGGL(paint_stroke_closed_kernel, dim3((2 * n_vertices * kPaintLanes + 255) / 256, n_frames), dim3(256), 0, st, d_verts,
+                       n_vertices, W, H, W32, rows, d_disc_plane, disc_static ? 1 : 0,
+                       reinterpret_cast<const uint32_t*>(d_pen_rgb), d_frames);
+    hipLaunchKernelGGL(paint_disc_multi_rows_kernel, dim3((n_frames * H + 255) / 256), dim3(256), 0, st, rows,
+                       d_disc_plane, disc_static ? 1 : 0, W, H, W32, n_frames, d_frames);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

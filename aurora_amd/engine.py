@@ -381,6 +381,8 @@ class HipExportEngine:
         self._glow_work = None
         self._base = None
         self.fill_events = None           # benchmarks set a list: (start, end, n_frames) HIP events around every plane fill
+        import os
+        self.direct_stroke = os.environ.get("AUR_DIRECT_STROKE", "1") != "0"   # A/B knob: 0 = always through the stroke plane
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):
@@ -932,6 +934,27 @@ class HipExportEngine:
             ev.append((e0, e1, count))
         return out
 
+    def raster_closed_path(self, verts, disc, static, pen_rgb, W: int, H: int, out):
+        """Closed-path frames without a stroke plane (aur_raster_closed_path): background / disc rows, then the stroke
+        painted straight into the frames."""
+        count = int(verts.shape[0])
+        ev = self.fill_events
+        if ev is not None:
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(self.lib.aur_raster_closed_path(self.ctx.handle, _ptr(verts), int(verts.shape[1]), count, W, H,
+                                                   _ptr(disc), int(static), _ptr(pen_rgb), _ptr(out), self.stream()),
+                   "aur_raster_closed_path")
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1, count))
+        return out
+
+    def _direct_stroke_ok(self, W: int, out, decorated: bool):
+        """No translucent layer needs the stroke plane as an exclusion mask, and the frame shape is the linear fill's."""
+        return (self.direct_stroke and not decorated and W % 32 == 0 and out is not None and out.is_contiguous()
+                and out.data_ptr() % 16 == 0)
+
     def render_radial(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int = 0,
                       count: int | None = None, out=None, planes_out=None, fill: FillConfig | None = None,
                       shadow: ShadowConfig | None = None, glow: GlowConfig | None = None):
@@ -940,11 +963,20 @@ class HipExportEngine:
         the translucent layers are applied afterwards where those two do not cover them."""
         if count is None:
             count = an.n_frames - first
-        planes = self.radial_planes(prep, an, sc, W, H, first, count, planes_out)
-        out = self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
         want_fill = fill is not None and fill.enabled
         want_shadow = shadow is not None and shadow.active
         want_glow = glow is not None and glow.active
+        if out is None:
+            out = self.empty((count, H, W, 3), self.torch.uint8)
+        if self._direct_stroke_ok(W, out, want_fill or want_shadow or want_glow):
+            disc = (self._static_disc(prep, an, sc, W, H, first)["full"]
+                    if (prep.cfg.disc_static and prep.image is None) else self._no_disc_plane(W, H))
+            self.raster_closed_path(self.radial_path_vertices(prep, sc, W, H, first, count), disc, True,
+                                    sc.pen_rgb[first:first + count], W, H, out)
+            planes = None
+        else:
+            planes = self.radial_planes(prep, an, sc, W, H, first, count, planes_out)
+            self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
         if want_fill or want_shadow or want_glow:
             verts = self.radial_path_vertices(prep, sc, W, H, first, count)
         if want_fill:
@@ -1027,11 +1059,17 @@ class HipExportEngine:
         """Frames uint8 [count, H, W, 3] of "Waveform - Circular" (paint_frame, rt_widget.py:821-852)."""
         if count is None:
             count = an.n_frames - first
-        planes = self.wave_circular_planes(an, sc, W, H, first, count, rotation_deg, planes_out)
-        out = self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
         want_fill = fill is not None and fill.enabled
         want_shadow = shadow is not None and shadow.active
         want_glow = glow is not None and glow.active
+        if out is None:
+            out = self.empty((count, H, W, 3), self.torch.uint8)
+        if self._direct_stroke_ok(W, out, want_fill or want_shadow or want_glow):
+            self.raster_closed_path(self.wave_circular_vertices(an, sc, W, H, first, count, rotation_deg),
+                                    self._no_disc_plane(W, H), True, sc.pen_rgb[first:first + count], W, H, out)
+            return out
+        planes = self.wave_circular_planes(an, sc, W, H, first, count, rotation_deg, planes_out)
+        self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)
         if want_fill or want_shadow or want_glow:
             verts = self.wave_circular_vertices(an, sc, W, H, first, count, rotation_deg)
         if want_fill:

@@ -400,6 +400,15 @@ int aur_compose_background(aur_ctx* ctx, const uint32_t* d_image, int img_w, int
  * or the context is destroyed; W, H must match the frames rendered afterwards. */
 int aur_set_background(aur_ctx* ctx, const uint8_t* d_base, int W, int H);
 
+/* A batch of closed-path frames in one call and without a stroke plane, for renders that need none afterwards (no fill /
+ * shadow / glow decoration): pass 1 of aur_raster_planes (background or base frame, disc rows), then the width-2 BevelJoin
+ * stroke of d_verts painted straight into the frames in the pen colour, leaving out what the disc covers.  The same frames
+ * as aur_mask_stroke_closed + aur_raster_planes, bit for bit, without the plane clear, the stroke plane and the patch pass.
+ * Widths that are multiples of 32 and 16-byte aligned batches only: AUR_EUNSUPPORTED otherwise (use the two calls). */
+int aur_raster_closed_path(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
+                           const uint32_t* d_disc_plane, int disc_static, const uint8_t* d_pen_rgb, uint8_t* d_frames,
+                           void* stream);
+
 /* ---- wire format ------------------------------------------------------------------------------- */
 
 /* Opt-in planar yuv420p wire format: the reference pipes rgb24 into FFmpeg

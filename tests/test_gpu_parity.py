@@ -1149,3 +1149,59 @@ def test_polygon_fill_with_hundreds_of_crossings_per_row(eng, size):
         assert ncross > (32 if n <= 384 else 150) and (n < 3000 or ncross > 256)   # beyond the former per-row limits
         assert np.array_equal(planes[0], planes[1])
         assert np.array_equal(planes[0], want), int(np.count_nonzero(planes[0] != want))
+
+
+@pytest.mark.parametrize("mode", ["Spectrum - Radial", "Waveform - Circular"])
+@pytest.mark.parametrize("size", [(640, 360), (1280, 200), (352, 288)])
+def test_closed_path_without_a_stroke_plane(eng, mode, size):
+    """aur_raster_closed_path (pass 1, then the stroke painted straight into the frames) against aur_mask_stroke_closed +
+    aur_raster_planes: byte-identical frames through the pipeline."""
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    W, H = size
+    track = eng.upload_track(synth.pink(9000, 2, seed=12), 48000, 60)
+    pipe = FramePipeline(eng, track, mode, W, H)
+    assert eng.direct_stroke
+    try:
+        fast = _np(pipe.render_device())
+        eng.direct_stroke = False
+        slow = _np(pipe.render_device())
+    finally:
+        eng.direct_stroke = True
+    assert np.array_equal(fast, slow), int(np.sum(fast != slow))
+
+
+@pytest.mark.parametrize("disc_kind", ["static", "static_holes", "per_frame_mixed"])
+def test_closed_path_entry_with_irregular_discs(eng, disc_kind):
+    """The same entry point against the two calls with disc planes a real export never produces: rows split into several
+    intervals (painted by the multi-row kernel, left out by the stroke), empty planes, one plane per frame."""
+    import ctypes as C
+    import torch
+    from aurora_amd import _lib, synth
+    W, H, F = 640, 200, 5
+    track = eng.upload_track(synth.pink(800 * F, 2, seed=21), 48000, 60)
+    an = eng.analyze(track, want_samples=True)
+    sc = eng.scan(an)
+    verts = eng.wave_circular_vertices(an, sc, W, H, 0, F)
+    rng = np.random.default_rng(5)
+    nd = 1 if disc_kind.startswith("static") else F
+    yy, xx = np.mgrid[0:H, 0:W]
+    disc = np.zeros((nd, H, W), bool)
+    for f in range(nd):
+        cx, cy, rad = W / 2 + 9 * f, H / 2, 0.33 * H
+        disc[f] = (xx - cx) ** 2 + (yy - cy) ** 2 <= rad * rad
+        if disc_kind == "static_holes" or (disc_kind == "per_frame_mixed" and f % 2 == 1):
+            disc[f, :, int(cx) - 3:int(cx) + 4] = False
+        if disc_kind == "per_frame_mixed" and f == 2:
+            disc[f] = False
+    packed = np.packbits(disc.reshape(nd, H, W // 32, 32), axis=-1, bitorder="little").view(np.uint32)[..., 0]
+    d_disc = torch.from_numpy(packed.view(np.int32)).to(eng.device)
+    pen = sc.pen_rgb[:F]
+    stroke = torch.empty((F, H, W // 32), dtype=torch.int32, device=eng.device)
+    _lib.check(eng.lib.aur_mask_stroke_closed(eng.ctx.handle, C.c_void_p(verts.data_ptr()), 1024, F, W, H,
+                                              C.c_void_p(stroke.data_ptr()), eng.stream()), "stroke")
+    want = _np(eng.fill_planes((stroke, d_disc, nd == 1), pen, W, H))
+    got = torch.full((F, H, W, 3), 0x5A, dtype=torch.uint8, device=eng.device)
+    eng.raster_closed_path(verts, d_disc, nd == 1, pen, W, H, got)
+    assert np.array_equal(_np(got), want), int(np.sum(_np(got) != want))
+    assert (want == np.asarray(R.DISC_RGB, np.uint8)).all(axis=3).sum() > 0

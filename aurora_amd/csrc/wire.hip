@@ -5,6 +5,8 @@
 // below the HBM rate of the rasteriser, so the conversion can run on the GPU instead: planar yuv420p is 1.5 B per pixel,
 // half the readback bytes, and FFmpeg is then started with "-pix_fmt yuv420p" for its input.
 // This is opt-in (view_state["hip_wire_format"] = "yuv420p"): the default wire format stays the reference's rgb24.
+// "nv12" is the same conversion with the chroma interleaved (one Cb Cr plane), the layout the reference asks FFmpeg's
+// swscale for in front of the VAAPI encoders (exporter.py:459-466 "-vf format=nv12,hwupload ... -pix_fmt nv12").
 //
 // Conversion (stated in full because FFmpeg is not available to pin it; oracle/wire_ref.py restates it in numpy):
 // ITU-R BT.601, limited range, 8-bit integer form
@@ -17,8 +19,23 @@
 
 namespace {
 
+// Chroma of one lane's two 2x2 blocks (u, v: two bytes each) of row pair y2.  Planar (yuv420p): a Cb plane, then a Cr
+// plane, W/2 bytes per row.  Semi-planar (nv12): one plane of interleaved Cb Cr pairs, W bytes per row.
+template <bool NV12>
+__device__ __forceinline__ void store_chroma(uint8_t* dst, size_t frame_px, int W, int y2, int x4, uint32_t u, uint32_t v) {
+    if (NV12) {
+        const uint32_t uv = (u & 255u) | ((v & 255u) << 8) | ((u >> 8) << 16) | ((v >> 8) << 24);
+        *reinterpret_cast<uint32_t*>(dst + frame_px + (size_t)y2 * W + 4 * x4) = uv;
+    } else {
+        const size_t coff = (size_t)y2 * (W / 2) + 2 * x4;
+        *reinterpret_cast<uint16_t*>(dst + frame_px + coff) = (uint16_t)u;
+        *reinterpret_cast<uint16_t*>(dst + frame_px + frame_px / 4 + coff) = (uint16_t)v;
+    }
+}
+
 // One lane: 4 pixels x 2 rows.  A wave reads 768 contiguous bytes of each of the two rows (12 B per lane, dwordx3),
 // writes 256 contiguous bytes of each Y row and 128 contiguous bytes of the U and of the V row.
+template <bool NV12>
 __global__ __launch_bounds__(256) void rgb24_to_yuv420p_kernel(const uint8_t* __restrict__ rgb, int W, int H,
                                                                uint8_t* __restrict__ yuv) {
     const int f = blockIdx.z;
@@ -64,9 +81,7 @@ __global__ __launch_bounds__(256) void rgb24_to_yuv420p_kernel(const uint8_t* __
         u |= (uint32_t)Cb << (8 * b);
         v |= (uint32_t)Cr << (8 * b);
     }
-    const size_t coff = (size_t)y2 * (W / 2) + 2 * x4;
-    *reinterpret_cast<uint16_t*>(dst + frame_px + coff) = (uint16_t)u;
-    *reinterpret_cast<uint16_t*>(dst + frame_px + frame_px / 4 + coff) = (uint16_t)v;
+    store_chroma<NV12>(dst, frame_px, W, y2, x4, u, v);
 }
 
 // ---- spans -> yuv420p directly (the span modes with the opt-in wire format) -------------------------------------------
@@ -77,7 +92,7 @@ __global__ __launch_bounds__(256) void rgb24_to_yuv420p_kernel(const uint8_t* __
 constexpr int kPairs = 8;
 constexpr int kBgR = 13, kBgG = 13, kBgB = 18;                  // QColor(13, 13, 18), rt_widget.py:829
 
-template <int K>
+template <int K, bool NV12>
 __global__ __launch_bounds__(256) void spans_to_yuv420p_kernel(const uint32_t* __restrict__ spans,
                                                                const uint32_t* __restrict__ pen_rgb, int W, int H,
                                                                uint8_t* __restrict__ yuv) {
@@ -134,54 +149,73 @@ __global__ __launch_bounds__(256) void spans_to_yuv420p_kernel(const uint32_t* _
             u |= (uint32_t)Cb << (8 * b);
             v |= (uint32_t)Cr << (8 * b);
         }
-        const size_t coff = (size_t)pr2 * (W / 2) + 2 * x4;
-        *reinterpret_cast<uint16_t*>(dst + frame_px + coff) = (uint16_t)u;
-        *reinterpret_cast<uint16_t*>(dst + frame_px + frame_px / 4 + coff) = (uint16_t)v;
+        store_chroma<NV12>(dst, frame_px, W, pr2, x4, u, v);
     }
+}
+
+template <bool NV12>
+int raster_spans_planar(const char* who, aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb,
+                        int n_frames, int W, int H, uint8_t* d_yuv, void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "%s: n_frames %d outside [0, 65535]", who, n_frames);
+    AUR_REQUIRE(W >= 64 && W <= 16384 && H >= 16 && H <= 16384, "%s: frame size %dx%d unsupported", who, W, H);
+    AUR_REQUIRE(W % 4 == 0 && H % 2 == 0, "%s: %dx%d: width must be a multiple of 4, height even", who, W, H);
+    AUR_REQUIRE(K == 2 || K == 5, "%s: K=%d unsupported (2 or 5)", who, K);
+    AUR_REQUIRE(ctx->d_base == nullptr, "%s: a background image is set; render rgb24 and convert (aur_rgb24_to_%s)", who,
+                NV12 ? "nv12" : "yuv420p");
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_spans && d_pen_rgb && d_yuv, "%s: null device pointer", who);
+    AUR_REQUIRE(((uintptr_t)d_spans & 15u) == 0 && ((uintptr_t)d_pen_rgb & 3u) == 0 && ((uintptr_t)d_yuv & 3u) == 0,
+                "%s: misaligned device pointer", who);
+    const dim3 grid((W / 4 + 255) / 256, (H / 2 + kPairs - 1) / kPairs, n_frames);
+    const uint32_t* pen = reinterpret_cast<const uint32_t*>(d_pen_rgb);
+    if (K == 2)
+        hipLaunchKernelGGL((spans_to_yuv420p_kernel<2, NV12>), grid, dim3(256), 0, (hipStream_t)stream, d_spans, pen, W, H,
+                           d_yuv);
+    else
+        hipLaunchKernelGGL((spans_to_yuv420p_kernel<5, NV12>), grid, dim3(256), 0, (hipStream_t)stream, d_spans, pen, W, H,
+                           d_yuv);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
+template <bool NV12>
+int rgb24_to_planar(const char* who, aur_ctx* ctx, const uint8_t* d_rgb, int n_frames, int W, int H, uint8_t* d_yuv,
+                    void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "%s: n_frames %d outside [0, 65535]", who, n_frames);
+    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "%s: frame size %dx%d unsupported", who, W, H);
+    AUR_REQUIRE(W % 4 == 0 && H % 2 == 0, "%s: %dx%d: width must be a multiple of 4, height even", who, W, H);
+    if (n_frames == 0) return AUR_OK;
+    AUR_REQUIRE(d_rgb && d_yuv, "%s: null device pointer", who);
+    AUR_REQUIRE(((uintptr_t)d_rgb & 3u) == 0 && ((uintptr_t)d_yuv & 3u) == 0, "%s: device pointers must be 4-byte aligned",
+                who);
+    hipLaunchKernelGGL(rgb24_to_yuv420p_kernel<NV12>, dim3((W / 4 + 255) / 256, H / 2, n_frames), dim3(256), 0,
+                       (hipStream_t)stream, d_rgb, W, H, d_yuv);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
 }
 
 }  // namespace
 
 extern "C" int aur_raster_spans_yuv420p(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb,
                                         int n_frames, int W, int H, uint8_t* d_yuv, void* stream) {
-    int rc = aur_use_device(ctx);
-    if (rc) return rc;
-    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_raster_spans_yuv420p: n_frames %d outside [0, 65535]", n_frames);
-    AUR_REQUIRE(W >= 64 && W <= 16384 && H >= 16 && H <= 16384, "aur_raster_spans_yuv420p: frame size %dx%d unsupported",
-                W, H);
-    AUR_REQUIRE(W % 4 == 0 && H % 2 == 0, "aur_raster_spans_yuv420p: %dx%d: width must be a multiple of 4, height even",
-                W, H);
-    AUR_REQUIRE(K == 2 || K == 5, "aur_raster_spans_yuv420p: K=%d unsupported (2 or 5)", K);
-    AUR_REQUIRE(ctx->d_base == nullptr,
-                "aur_raster_spans_yuv420p: a background image is set; render rgb24 and convert (aur_rgb24_to_yuv420p)");
-    if (n_frames == 0) return AUR_OK;
-    AUR_REQUIRE(d_spans && d_pen_rgb && d_yuv, "aur_raster_spans_yuv420p: null device pointer");
-    AUR_REQUIRE(((uintptr_t)d_spans & 15u) == 0 && ((uintptr_t)d_pen_rgb & 3u) == 0 && ((uintptr_t)d_yuv & 3u) == 0,
-                "aur_raster_spans_yuv420p: misaligned device pointer");
-    const dim3 grid((W / 4 + 255) / 256, (H / 2 + kPairs - 1) / kPairs, n_frames);
-    const uint32_t* pen = reinterpret_cast<const uint32_t*>(d_pen_rgb);
-    if (K == 2)
-        hipLaunchKernelGGL(spans_to_yuv420p_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, d_spans, pen, W, H, d_yuv);
-    else
-        hipLaunchKernelGGL(spans_to_yuv420p_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, d_spans, pen, W, H, d_yuv);
-    AUR_CHECK_HIP(hipGetLastError());
-    return AUR_OK;
+    return raster_spans_planar<false>("aur_raster_spans_yuv420p", ctx, d_spans, K, d_pen_rgb, n_frames, W, H, d_yuv, stream);
+}
+
+extern "C" int aur_raster_spans_nv12(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb, int n_frames,
+                                     int W, int H, uint8_t* d_nv12, void* stream) {
+    return raster_spans_planar<true>("aur_raster_spans_nv12", ctx, d_spans, K, d_pen_rgb, n_frames, W, H, d_nv12, stream);
 }
 
 extern "C" int aur_rgb24_to_yuv420p(aur_ctx* ctx, const uint8_t* d_rgb, int n_frames, int W, int H, uint8_t* d_yuv,
                                     void* stream) {
-    int rc = aur_use_device(ctx);
-    if (rc) return rc;
-    AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_rgb24_to_yuv420p: n_frames %d outside [0, 65535]", n_frames);
-    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_rgb24_to_yuv420p: frame size %dx%d unsupported", W,
-                H);
-    AUR_REQUIRE(W % 4 == 0 && H % 2 == 0, "aur_rgb24_to_yuv420p: %dx%d: width must be a multiple of 4, height even", W, H);
-    if (n_frames == 0) return AUR_OK;
-    AUR_REQUIRE(d_rgb && d_yuv, "aur_rgb24_to_yuv420p: null device pointer");
-    AUR_REQUIRE(((uintptr_t)d_rgb & 3u) == 0 && ((uintptr_t)d_yuv & 3u) == 0,
-                "aur_rgb24_to_yuv420p: device pointers must be 4-byte aligned");
-    hipLaunchKernelGGL(rgb24_to_yuv420p_kernel, dim3((W / 4 + 255) / 256, H / 2, n_frames), dim3(256), 0,
-                       (hipStream_t)stream, d_rgb, W, H, d_yuv);
-    AUR_CHECK_HIP(hipGetLastError());
-    return AUR_OK;
+    return rgb24_to_planar<false>("aur_rgb24_to_yuv420p", ctx, d_rgb, n_frames, W, H, d_yuv, stream);
+}
+
+extern "C" int aur_rgb24_to_nv12(aur_ctx* ctx, const uint8_t* d_rgb, int n_frames, int W, int H, uint8_t* d_nv12,
+                                 void* stream) {
+    return rgb24_to_planar<true>("aur_rgb24_to_nv12", ctx, d_rgb, n_frames, W, H, d_nv12, stream);
 }

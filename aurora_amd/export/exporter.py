@@ -315,7 +315,7 @@ def _encoder_plan(prefer_hevc: bool, gpu_device: Optional[str]):
 
 
 def _check_pix_fmt(input_pix_fmt):
-    if input_pix_fmt not in ("rgb24", "yuv420p"):
+    if input_pix_fmt not in ("rgb24", "yuv420p", "nv12"):
         raise ValueError(f"input_pix_fmt {input_pix_fmt!r}")
 
 
@@ -323,7 +323,8 @@ def build_ffmpeg_cmd(width: int, height: int, fps: int, out_path: str, audio_pat
                      prefer_hevc: bool = False, gpu_device: Optional[str] = None,
                      input_pix_fmt: str = "rgb24") -> Tuple[List[str], str]:
     """FFmpeg argv for rawvideo WxH@fps on stdin + the audio file (exporter.py:413-491).  ``input_pix_fmt`` is the
-    reference's "rgb24" unless the renderer was asked for the yuv420p wire format (view_state["hip_wire_format"])."""
+    reference's "rgb24" unless the renderer was asked for the yuv420p or nv12 wire format (view_state["hip_wire_format"];
+    nv12 is what the VAAPI chain "format=nv12,hwupload" converts to, :464-466, so that filter then passes frames through)."""
     _check_pix_fmt(input_pix_fmt)
     out_path = _ensure_ext(out_path, ".mp4")
     ffmpeg, dev_args, vfilter, codec, vflags, pix_out = _encoder_plan(prefer_hevc, gpu_device)

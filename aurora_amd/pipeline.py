@@ -87,10 +87,11 @@ class FramePipeline:
         self.batch = int(batch_frames or default_batch_frames(self.W, self.H))
         self.slots = int(max(1, slots))
         self.params = scan_params or _lib.ScanParams.defaults(sensitivity)
-        if wire_format not in ("rgb24", "yuv420p"):
-            raise ValueError(f"wire_format {wire_format!r}: expected 'rgb24' (the reference's, exporter.py:429-434) or 'yuv420p'")
-        if wire_format == "yuv420p" and (self.W % 4 or self.H % 2):
-            raise ValueError("yuv420p wire format needs a width that is a multiple of 4 and an even height")
+        if wire_format not in ("rgb24", "yuv420p", "nv12"):
+            raise ValueError(f"wire_format {wire_format!r}: expected 'rgb24' (the reference's, exporter.py:429-434), "
+                             "'yuv420p' or 'nv12'")
+        if wire_format != "rgb24" and (self.W % 4 or self.H % 2):
+            raise ValueError(f"{wire_format} wire format needs a width that is a multiple of 4 and an even height")
         self.wire_format = wire_format
         self.rgb_bytes = self.W * self.H * 3
         # bytes per frame on the wire (readback, sink)
@@ -189,7 +190,7 @@ class FramePipeline:
         n_total = max(1, self.frame_end - self.frame_begin)
         B, S = min(self.batch, n_total), self.slots
         dev_frames = [eng.empty((B, self.H, self.W, 3), torch.uint8) for _ in range(S)]
-        yuv = self.wire_format == "yuv420p"
+        yuv = self.wire_format != "rgb24"
         dev_wire = [eng.empty((B, self.frame_bytes), torch.uint8) for _ in range(S)] if yuv else dev_frames
         if self.planes:
             dev_spans = [eng.empty((2, B, self.H, (self.W + 31) // 32), torch.int32) for _ in range(S)]
@@ -203,7 +204,7 @@ class FramePipeline:
         return self
 
     def _fused_yuv_ok(self):
-        """yuv420p straight from the spans: span modes without a background image or a shadow layer."""
+        """yuv420p / nv12 straight from the spans: span modes without a background image or a shadow layer."""
         return (not self.planes and self.background is None and self.shadow is None
                 and self.W % 4 == 0 and self.H % 2 == 0)
 
@@ -233,7 +234,8 @@ class FramePipeline:
         B, S = ring["B"], ring["S"]
         dev_frames, dev_wire, dev_spans, host = ring["dev_frames"], ring["dev_wire"], ring["dev_spans"], ring["host"]
         copy_stream = ring["copy_stream"]
-        yuv = self.wire_format == "yuv420p"
+        yuv = self.wire_format != "rgb24"
+        nv12 = self.wire_format == "nv12"
         copied = [None] * S                    # event: slot's D2H copy finished
         free_slots = threading.Semaphore(S)    # host slot consumed by the writer
         q: "queue.Queue" = queue.Queue()
@@ -278,17 +280,19 @@ class FramePipeline:
                 if fused:
                     # span modes: the planar frame straight from the spans, no rgb24 frame in between
                     spans, K = eng.spans(self.kind, an, sc, self.W, self.H, done, n, out=dev_spans[slot][:n])
-                    _lib.check(eng.lib.aur_raster_spans_yuv420p(
+                    entry = eng.lib.aur_raster_spans_nv12 if nv12 else eng.lib.aur_raster_spans_yuv420p
+                    _lib.check(entry(
                         eng.ctx.handle, C.c_void_p(spans.data_ptr()), K, C.c_void_p(sc.pen_rgb[done:done + n].data_ptr()),
                         n, self.W, self.H, C.c_void_p(dev_wire[slot].data_ptr()), eng.stream()),
-                        "aur_raster_spans_yuv420p")
+                        "aur_raster_spans_" + self.wire_format)
                 else:
                     self._render(an, sc, done, n, out=dev_frames[slot][:n],
                                  scratch=dev_spans[slot][:, :n] if self.planes else dev_spans[slot][:n])
                 if yuv and not fused:
-                    _lib.check(eng.lib.aur_rgb24_to_yuv420p(
+                    entry = eng.lib.aur_rgb24_to_nv12 if nv12 else eng.lib.aur_rgb24_to_yuv420p
+                    _lib.check(entry(
                         eng.ctx.handle, C.c_void_p(dev_frames[slot].data_ptr()), n, self.W, self.H,
-                        C.c_void_p(dev_wire[slot].data_ptr()), eng.stream()), "aur_rgb24_to_yuv420p")
+                        C.c_void_p(dev_wire[slot].data_ptr()), eng.stream()), "aur_rgb24_to_" + self.wire_format)
                 rendered = torch.cuda.Event()
                 rendered.record(cur)
                 copy_stream.wait_event(rendered)

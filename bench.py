@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument("--glow", action="store_true", help="closed-path modes: add the glow decoration (7 additive strokes)")
     ap.add_argument("--batch", type=int, default=64, help="frames per raster launch / ring slot")
     ap.add_argument("--slots", type=int, default=3, help="ring slots in flight")
-    ap.add_argument("--wire", default="rgb24", choices=("rgb24", "yuv420p"), help="wire format of the headline leg")
+    ap.add_argument("--wire", default="rgb24", choices=("rgb24", "yuv420p", "nv12"), help="wire format of the headline leg")
     ap.add_argument("--device-seconds", type=float, default=3600.0, help="track of the device-side leg (configs[4] unit)")
     ap.add_argument("--device-steps", type=int, default=2, help="timed steps of the device-side leg (0 = skip)")
     ap.add_argument("--device-warmup", type=int, default=1, help="untimed steps of the device-side leg")

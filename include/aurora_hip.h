@@ -426,6 +426,14 @@ int aur_rgb24_to_yuv420p(aur_ctx* ctx, const uint8_t* d_rgb, int n_frames, int W
 int aur_raster_spans_yuv420p(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb, int n_frames, int W,
                              int H, uint8_t* d_yuv, void* stream);
 
+/* The same two conversions into nv12, the semi-planar layout FFmpeg's VAAPI encoders take (the reference asks FFmpeg for
+ * "-vf format=nv12,hwupload ... -pix_fmt nv12" on that path, export/exporter.py:459-466, and leaves the rgb24 -> nv12
+ * conversion to swscale): Y [H, W], then one plane [H/2, W] of interleaved Cb Cr pairs.  Same arithmetic, same
+ * constraints, same size (W*H*3/2 per frame) as the yuv420p entries; opt-in, view_state["hip_wire_format"] = "nv12". */
+int aur_rgb24_to_nv12(aur_ctx* ctx, const uint8_t* d_rgb, int n_frames, int W, int H, uint8_t* d_nv12, void* stream);
+int aur_raster_spans_nv12(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb, int n_frames, int W,
+                          int H, uint8_t* d_nv12, void* stream);
+
 /* ---- readback ---------------------------------------------------------------------------------- */
 
 /* Pinned host memory for the frame ring that feeds the FFmpeg pipe (replaces the arr.copy()/tobytes()

@@ -1,4 +1,4 @@
-"""ORACLE (test infrastructure, not product code): numpy restatement of the opt-in yuv420p wire format.
+"""ORACLE (test infrastructure, not product code): numpy restatement of the opt-in yuv420p / nv12 wire formats.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.
 
@@ -24,3 +24,13 @@ def rgb24_to_yuv420p(frame: np.ndarray) -> np.ndarray:
     cb = ((-38 * mr - 74 * mg + 112 * mb + 128) >> 8) + 128
     cr = ((112 * mr - 94 * mg - 18 * mb + 128) >> 8) + 128
     return np.concatenate([y.reshape(-1), cb.reshape(-1), cr.reshape(-1)]).astype(np.uint8)
+
+
+def rgb24_to_nv12(frame: np.ndarray) -> np.ndarray:
+    """uint8 [H, W, 3] -> uint8 [H * W * 3 // 2]: Y plane [H, W], then one plane [H/2, W] of interleaved Cb Cr pairs
+    (the layout the reference asks FFmpeg for on the VAAPI path, ``export/exporter.py:464-466``).  Same values as
+    ``rgb24_to_yuv420p``, chroma interleaved instead of planar."""
+    h, w, _ = frame.shape
+    p = rgb24_to_yuv420p(frame)
+    y, cb, cr = p[:h * w], p[h * w:h * w + h * w // 4], p[h * w + h * w // 4:]
+    return np.concatenate([y, np.stack([cb, cr], axis=1).reshape(-1)])

@@ -642,6 +642,12 @@ def test_yuv420p_wire_format_bit_exact(eng, size):
     for f in range(3):
         assert np.array_equal(got[f], WR.rgb24_to_yuv420p(rgb[f])), (size, f)
     assert got[1].min() == 235 or got[1][:W * H].min() == 235       # white -> Y 235, limited range
+    d_nv = torch.zeros_like(d_yuv)
+    _lib.check(eng.lib.aur_rgb24_to_nv12(eng.ctx.handle, C.c_void_p(d_rgb.data_ptr()), 3, W, H,
+                                         C.c_void_p(d_nv.data_ptr()), eng.stream()), "aur_rgb24_to_nv12")
+    got = _np(d_nv)
+    for f in range(3):
+        assert np.array_equal(got[f], WR.rgb24_to_nv12(rgb[f])), (size, f)
 
 
 def test_pipeline_yuv420p_stream(eng):
@@ -665,11 +671,12 @@ def test_pipeline_yuv420p_stream(eng):
         FramePipeline(eng, track, "Spectrum - Linear", 322, H, wire_format="yuv420p")
 
 
+@pytest.mark.parametrize("wire", ["yuv420p", "nv12"])
 @pytest.mark.parametrize("mode", ["Spectrum - Linear", "Waveform - Linear", "Particles", "Spectrum - Radial"])
 @pytest.mark.parametrize("size", [(320, 192), (1284, 94), (3840, 64)])
-def test_fused_yuv420p_fill(eng, mode, size):
-    """yuv420p wire format of every mode == the conversion of the same pipeline's rgb24 frames: the span modes take
-    aur_raster_spans_yuv420p (no rgb24 frame in between), the others render rgb24 and convert."""
+def test_fused_yuv420p_fill(eng, mode, size, wire):
+    """yuv420p / nv12 wire format of every mode == the conversion of the same pipeline's rgb24 frames: the span modes take
+    aur_raster_spans_yuv420p / _nv12 (no rgb24 frame in between), the others render rgb24 and convert."""
     import io
     from aurora_amd import synth
     from aurora_amd.pipeline import FramePipeline
@@ -678,13 +685,14 @@ def test_fused_yuv420p_fill(eng, mode, size):
     track = eng.upload_track(synth.pink(5000, 2, seed=13), 48000, 60)
     rgb = _np(FramePipeline(eng, track, mode, W, H).render_device())
     buf = io.BytesIO()
-    pipe = FramePipeline(eng, track, mode, W, H, batch_frames=3, wire_format="yuv420p")
+    pipe = FramePipeline(eng, track, mode, W, H, batch_frames=3, wire_format=wire)
     assert pipe._fused_yuv_ok() == (not mode.endswith("Radial"))
+    convert = WR.rgb24_to_nv12 if wire == "nv12" else WR.rgb24_to_yuv420p
     n = pipe.run(buf)
     raw = np.frombuffer(buf.getvalue(), np.uint8).reshape(n, W * H * 3 // 2)
     assert n == rgb.shape[0]
     for f in range(n):
-        assert np.array_equal(raw[f], WR.rgb24_to_yuv420p(rgb[f])), (mode, size, f)
+        assert np.array_equal(raw[f], convert(rgb[f])), (mode, size, wire, f)
 
 
 # ------------------------------------------------------------------ feather rings

@@ -293,6 +293,18 @@ def test_yuv420p_oracle_known_answers():
     assert (y, cb, cr) == (28, 130, 128)              # (66*13 + 129*13 + 25*18 + 128 >> 8) + 16 = 12 + 16
 
 
+def test_nv12_oracle_is_the_interleaved_yuv420p():
+    from oracle import wire_ref as WR
+    rng = np.random.default_rng(8)
+    f = rng.integers(0, 256, size=(6, 8, 3), dtype=np.uint8)
+    p, s = WR.rgb24_to_yuv420p(f), WR.rgb24_to_nv12(f)
+    assert s.shape == p.shape and np.array_equal(s[:48], p[:48])
+    assert np.array_equal(s[48::2], p[48:60]) and np.array_equal(s[49::2], p[60:])      # Cb Cr Cb Cr ...
+    g = np.empty((2, 4, 3), np.uint8)
+    g[:] = (255, 0, 0)
+    assert WR.rgb24_to_nv12(g).tolist() == [82] * 8 + [90, 240, 90, 240]
+
+
 def test_blend_rule_is_qt_premultiplied_source_over():
     # alpha 255 overwrites, alpha 0 keeps, and the six feather alphas over the disc colour give the documented value
     f = np.zeros((2, 2, 3), np.uint8)
@@ -311,6 +323,8 @@ def test_new_entry_points_reject_bad_arguments_without_gpu():
     lib = _lib.load()
     # every call fails on the null context before touching a device
     assert lib.aur_rgb24_to_yuv420p(None, None, 1, 64, 64, None, None) != 0
+    assert lib.aur_rgb24_to_nv12(None, None, 1, 64, 64, None, None) != 0
+    assert lib.aur_raster_spans_nv12(None, None, 2, None, 1, 64, 64, None, None) != 0
     assert lib.aur_blend_planes(None, None, 6, b"\0" * 24, 1, 64, 64, None, None) != 0
     assert lib.aur_add_planes(None, None, 7, None, None, None, 0, 1, 64, 64, None, None) != 0
     assert lib.aur_wave_circular_vertices(None, None, None, 1, None, 64, 64, None, None) != 0
@@ -409,6 +423,25 @@ def test_ffmpeg_argv_and_device_list_match_reference_matrix():
     assert got.keys() == want.keys() and len(want) == 864 + 27
     bad = [k for k in want if got[k] != want[k]]
     assert not bad, (bad[:5], got[bad[0]], want[bad[0]])
+
+
+def test_ffmpeg_argv_with_the_opt_in_wire_formats(monkeypatch):
+    """Only the input "-pix_fmt" changes with view_state["hip_wire_format"]; on the VAAPI path an nv12 input is what the
+    reference's own filter chain "format=nv12,hwupload" (export/exporter.py:464) converts to."""
+    from aurora_amd.export import exporter as mine
+    monkeypatch.setattr(mine, "_ffmpeg_bin", lambda: "ffmpeg")
+    monkeypatch.setattr(mine, "_ffmpeg_encoders", lambda ffmpeg: {"libx264", "h264_vaapi", "hevc_vaapi"})
+    monkeypatch.setattr(mine.platform, "system", lambda: "Linux")
+    ref, fmt = mine.build_ffmpeg_cmd(1920, 1080, 60, "out", "a.wav", gpu_device="vaapi:/dev/dri/renderD128")
+    assert fmt == "rgb24" and ref[ref.index("-vf") + 1] == "format=nv12,hwupload" and ref[-1] == "out.mp4"
+    for wire in ("yuv420p", "nv12"):
+        cmd, fmt = mine.build_ffmpeg_cmd(1920, 1080, 60, "out", "a.wav", gpu_device="vaapi:/dev/dri/renderD128",
+                                         input_pix_fmt=wire)
+        assert fmt == wire
+        i = cmd.index("-pix_fmt")
+        assert cmd[i + 1] == wire and cmd[:i + 1] == ref[:i + 1] and cmd[i + 2:] == ref[i + 2:]
+    with pytest.raises(ValueError):
+        mine.build_ffmpeg_cmd(64, 64, 30, "out", "a.wav", input_pix_fmt="nv21")
 
 
 class _DuckRenderer:

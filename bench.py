@@ -53,7 +53,9 @@ def parse_args():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--mode", default="Spectrum - Linear")
     ap.add_argument("--glow", action="store_true", help="closed-path modes: add the glow decoration (7 additive strokes)")
-    ap.add_argument("--batch", type=int, default=64, help="frames per raster launch / ring slot")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per raster launch / ring slot (0 = as many as fit the 1.6 GB of 64 4K frames: small "
+                         "frames in small batches leave the device leg bound by the host's launch rate)")
     ap.add_argument("--slots", type=int, default=3, help="ring slots in flight")
     ap.add_argument("--wire", default="rgb24", choices=("rgb24", "yuv420p", "nv12"), help="wire format of the headline leg")
     ap.add_argument("--device-seconds", type=float, default=3600.0, help="track of the device-side leg (configs[4] unit)")
@@ -161,6 +163,8 @@ def main():
     eng = get_engine(dev_index)
     sr, fps, W, H = args.sample_rate, args.fps, args.width, args.height
     frame_bytes = W * H * 3
+    if args.batch <= 0:
+        args.batch = int(max(8, min(1024, (64 * 3840 * 2160 * 3) // frame_bytes)))
 
     def barrier():
         if world > 1:

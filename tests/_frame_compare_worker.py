@@ -21,3 +21,27 @@ def compare_frame(task):
         return res
     finally:
         shm.close()
+
+
+def compare_closed_frame(task):
+    """The closed-path modes: the oracle's own vertices (from the oracle's own analysis) rasterised by the oracle, against
+    the GPU frame in shared memory.  Same triple as compare_frame."""
+    from multiprocessing import shared_memory
+    from oracle import raster_ref as R
+    shm_name, offset, mode, path, env, pen, W, H = task
+    shm = shared_memory.SharedMemory(name=shm_name)
+    try:
+        got = np.ndarray((H, W, 3), dtype=np.uint8, buffer=shm.buf, offset=offset)
+        if mode == "Spectrum - Radial":
+            want = R.render_radial_frame(path, env, pen, W, H)
+        else:
+            want = R.render_wave_circular_frame(path, pen, W, H)
+        if np.array_equal(got, want):
+            res = (0, 0, float("inf"))
+        else:
+            d = np.abs(got.astype(np.int16) - want.astype(np.int16)).max(axis=2)
+            res = (int(np.count_nonzero(d)), int(np.count_nonzero(d > 1)), float(R.psnr(got, want)))
+        del got
+        return res
+    finally:
+        shm.close()

@@ -104,6 +104,82 @@ def test_frames_vs_oracle_own_spectrum(eng, track4min, pool, mode, size):
     assert rate <= MAX_RATE[mode], rate
 
 
+@pytest.mark.parametrize("mode,size,n_sampled", [("Spectrum - Radial", (1920, 1080), 480),
+                                                 ("Spectrum - Radial", (3840, 2160), 240),
+                                                 ("Waveform - Circular", (3840, 2160), 480)])
+def test_closed_path_frames_vs_oracle_own_chain(eng, track4min, pool, mode, size, n_sampled):
+    """The closed-path modes end to end: GPU audio -> GPU spectrum -> smoothing chain, `_radial_prev` EMA, vertices,
+    stroke, antialiased disc on the GPU, against the oracle's own chain from the oracle's own spectrum (radial_ref over
+    every frame of the track in order, then the oracle rasteriser on the sampled frames).  "Waveform - Circular" depends
+    on samples and energy only (bit-exact), so its frames must be identical; the radial path inherits the last-ulp
+    differences of log1p|X| through normalisation and smoothing, so an edge pixel may flip in a few frames: the rate is
+    printed and bounded."""
+    import torch
+    from _frame_compare_worker import compare_closed_frame
+    from aurora_amd.engine import RadialConfig
+    from oracle import radial_ref as RR
+    track, an, sc, ref, pen = track4min
+    W, H = size
+    F = track.total_frames
+    picks = np.unique(np.linspace(0, F - 1, n_sampled).astype(np.int64))
+    wanted = set(int(f) for f in picks)
+    radial = mode == "Spectrum - Radial"
+    paths, envs = {}, {}
+    if radial:
+        phase = A.phase_track(ref["energy"])
+        tr = RR.RadialTrack()
+        for f in range(F):                                         # the EMA is sequential: every frame, in order
+            if f in wanted:
+                paths[f] = tr.path(ref["logspec"][f], float(ref["energy"][f]), W, H)
+                envs[f] = RR.envelope_path(ref["logspec"][f], float(ref["energy"][f]), float(phase[f]), W, H)
+            else:
+                tr.values(ref["logspec"][f])
+        prep = eng.radial_prepare(an, RadialConfig())
+    else:
+        for f in wanted:
+            paths[f] = RR.wave_circular_path(ref["samples"][f], float(ref["energy"][f]), W, H)
+            envs[f] = None
+    fb = W * H * 3
+    shms = [shared_memory.SharedMemory(create=True, size=BATCH * fb) for _ in range(2)]
+    try:
+        views = [np.ndarray((BATCH, H, W, 3), dtype=np.uint8, buffer=s.buf) for s in shms]
+        dev = eng.empty((BATCH, H, W, 3), torch.uint8)
+        pending, results = None, []
+        for b0 in range(0, len(picks), BATCH):
+            group = [int(f) for f in picks[b0:b0 + BATCH]]
+            half = (b0 // BATCH) % 2
+            for j, f in enumerate(group):
+                if radial:
+                    eng.render_radial(prep, an, sc, W, H, f, 1, out=dev[j:j + 1])
+                else:
+                    eng.render_wave_circular(an, sc, W, H, f, 1, out=dev[j:j + 1])
+            host = dev[:len(group)].cpu().numpy()
+            if pending is not None:
+                results.extend(pending[0].get(timeout=600))       # the half written next was compared by this batch
+            views[half][:len(group)] = host
+            tasks = [(shms[half].name, j * fb, mode, paths[f], envs[f], pen[f], W, H) for j, f in enumerate(group)]
+            pending = (pool.map_async(compare_closed_frame, tasks), half)
+        results.extend(pending[0].get(timeout=600))
+        del views
+    finally:
+        for s in shms:
+            s.close()
+            s.unlink()
+    assert len(results) == len(picks)
+    ndiff = np.array([r[0] for r in results])
+    nbad = np.array([r[1] for r in results])
+    ps = np.array([r[2] for r in results])
+    flipped = int(np.count_nonzero(ndiff))
+    rate = flipped / len(picks)
+    print(f"\n{mode} {W}x{H}: {flipped} of {len(picks)} sampled frames differ from the oracle's own export "
+          f"(rate {rate:.5f}); worst frame: {int(ndiff.max())} pixels differ, {int(nbad.max())} by more than 1 LSB, "
+          f"min PSNR {ps.min():.1f} dB")
+    if radial:
+        assert ps.min() >= 50.0 and ndiff.max() <= 16 and rate <= 0.05, (rate, int(ndiff.max()))
+    else:
+        assert flipped == 0
+
+
 def _ulps(a, b):
     return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
 

@@ -18,7 +18,7 @@ ABI_VERSION = 1
 
 # every symbol include/aurora_hip.h declares (tests check the library exports exactly these)
 SYMBOLS = (
-    "aur_version", "aur_last_error", "aur_device_count", "aur_create", "aur_destroy", "aur_get_window",
+    "aur_version", "aur_last_error", "aur_device_count", "aur_device_pci_bus_id", "aur_create", "aur_destroy", "aur_get_window",
     "aur_stft_frames", "aur_mix_channels", "aur_stft_buffer", "aur_log1p_f32", "aur_scan_frames",
     "aur_spans_spectrum_linear", "aur_spans_particles", "aur_spans_waveform_linear", "aur_raster_spans",
     "aur_raster_work_bytes", "aur_span_summary", "aur_raster_spans_ws", "aur_raster_spans_static",
@@ -108,6 +108,7 @@ def _declare(lib):
     lib.aur_last_error.restype = C.c_char_p
     lib.aur_last_error.argtypes = []
     lib.aur_device_count.argtypes = [C.POINTER(i32)]
+    lib.aur_device_pci_bus_id.argtypes = [i32, C.c_char_p, i32]
     lib.aur_create.argtypes = [i32, C.POINTER(vp)]
     lib.aur_destroy.restype = None
     lib.aur_destroy.argtypes = [vp]

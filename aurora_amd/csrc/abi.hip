@@ -61,6 +61,12 @@ static void build_tables(float* window, double* tw) {
         }
 }
 
+extern "C" int aur_device_pci_bus_id(int device, char* out, int len) {
+    AUR_REQUIRE(out != nullptr && len >= 16, "aur_device_pci_bus_id: buffer of at least 16 bytes expected");
+    AUR_CHECK_HIP(hipDeviceGetPCIBusId(out, len, device));
+    return AUR_OK;
+}
+
 extern "C" int aur_create(int device, aur_ctx** out) {
     AUR_REQUIRE(out != nullptr, "aur_create: null out pointer");
     *out = nullptr;

@@ -117,6 +117,11 @@ def _export(cfg, exporter_mod) -> None:
         from aurora_amd.export import sharded
         sharded.export_sharded(cfg, gpus, progress, devices=vs.get("hip_devices"))   # default: devices 0 .. gpus-1
         return
+    if "hip_device" in vs and vs.get("hip_bind_numa", True):
+        # one of several workers on a multi-GPU node: keep this process (and the pinned frame ring it is about to
+        # allocate) on the socket its GPU hangs off
+        from aurora_amd import _lib, sharding
+        sharding.bind_near_device(_lib.load(), int(vs.get("hip_device") or 0))
     ex = exporter_mod.Exporter(**exporter_kwargs(cfg))
     raw_out = cfg.get("hip_raw_out")
     if not raw_out:

@@ -9,6 +9,8 @@ round-robin with ``track_assignment``.
 """
 from __future__ import annotations
 
+import os
+
 
 def frame_range(total_frames: int, world: int, rank: int) -> tuple[int, int]:
     """Contiguous, balanced [begin, end) of ``rank``; ranges of all ranks tile [0, total_frames) in rank order."""
@@ -51,3 +53,63 @@ def gather_digests_in_order(digest: str, n_bytes: int, dst: int = 0):
     out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
     dist.gather_object(rec, out, dst=dst)
     return out
+
+
+# ---- placement of a rank on the host ---------------------------------------------------------------------------------
+# Every exported frame crosses the GPU's PCIe link into a pinned host ring (24.9 MB per 4K frame, 57 GB/s per GPU).  On a
+# two-socket node the ring and the threads that drain it belong on the socket the GPU hangs off: a ring on the other
+# socket sends 8 x 57 GB/s of DMA writes over the inter-socket links.  One process per GPU makes this a matter of CPU
+# affinity: pages are allocated on the node of the thread that allocates (and HIP's own default picks the node nearest
+# the current device), so the rank binds itself before it allocates anything.
+
+def parse_cpulist(text: str) -> set:
+    """"0-15,128-143" -> {0..15, 128..143} (the format of /sys/.../local_cpulist)."""
+    cpus = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def device_numa(bus_id: str, sysfs: str = "/sys/bus/pci/devices"):
+    """(numa_node, cpus local to it) of the PCI device ``dddd:bb:dd.f``; (None, set()) where the host does not say
+    (single-node machines and most virtual machines report -1)."""
+    base = os.path.join(sysfs, bus_id.strip().lower())
+    try:
+        with open(os.path.join(base, "numa_node")) as fh:
+            node = int(fh.read().strip())
+        with open(os.path.join(base, "local_cpulist")) as fh:
+            cpus = parse_cpulist(fh.read())
+    except (OSError, ValueError):
+        return None, set()
+    return (node if node >= 0 else None), cpus
+
+
+def bind_near_device(lib, device: int, sysfs: str = "/sys/bus/pci/devices"):
+    """Restricts the calling process to the CPUs next to HIP device ``device`` (those it is allowed to use anyway).
+    Returns a dict describing what was done; never raises: a host that does not expose the topology is left alone."""
+    import ctypes as C
+    info = {"device": int(device), "bus_id": None, "numa_node": None, "bound_cpus": 0}
+    buf = C.create_string_buffer(64)
+    try:
+        if lib.aur_device_pci_bus_id(int(device), buf, 64) != 0:
+            return info
+    except Exception:
+        return info
+    info["bus_id"] = buf.value.decode("ascii", "ignore")
+    node, cpus = device_numa(info["bus_id"], sysfs)
+    info["numa_node"] = node
+    if node is None or not cpus or not hasattr(os, "sched_setaffinity"):
+        return info
+    try:
+        allowed = os.sched_getaffinity(0)
+        want = allowed & cpus
+        if want and want != allowed:
+            os.sched_setaffinity(0, want)
+        info["bound_cpus"] = len(want)
+    except OSError:
+        pass
+    return info

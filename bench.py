@@ -161,6 +161,8 @@ def main():
     from aurora_amd.pipeline import FramePipeline, NullSink
 
     eng = get_engine(dev_index)
+    # threads and the pinned frame ring of this rank on the socket its GPU hangs off (a no-op where the host hides it)
+    placement = sharding.bind_near_device(eng.lib, dev_index)
     sr, fps, W, H = args.sample_rate, args.fps, args.width, args.height
     frame_bytes = W * H * 3
     if args.batch <= 0:
@@ -378,7 +380,7 @@ def main():
                                    f"{args.mode}{' + glow' if args.glow else ''} {W}x{H}@{fps}, {F} frames per GPU per "
                                    f"step, every frame read back through a pinned ring into a null sink ({args.wire})",
                        "frames_per_gpu": F, "batch_frames": B, "ring_slots": args.slots, "wire_format": args.wire,
-                       "parallelism": f"time/track shards x{world}"},
+                       "parallelism": f"time/track shards x{world}", "host_placement_rank0": placement},
             "stft_gbs": roof_stft["achieved"] if roof_stft else None,
             "roofline": roof,
             "roofline_pcie": {"bound": "pcie", "achieved": round(link_gbs, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s",

@@ -52,6 +52,10 @@ typedef struct aur_ctx aur_ctx;
 int         aur_version(void);                 /* ABI version, bumped on incompatible change */
 const char* aur_last_error(void);              /* thread-local, never NULL */
 int         aur_device_count(int* out_count);
+/* PCI address "dddd:bb:dd.f" of a HIP device, so that the host side can place a rank's threads and its pinned frame ring
+ * on the NUMA node the GPU hangs off (aurora_amd/sharding.py: bind_near_device).  No counterpart in the reference, which
+ * exports in one process on the CPU (export/worker.py). */
+int         aur_device_pci_bus_id(int device, char* out, int len);
 
 /* Creates a context on `device`: uploads the Hann window (audio/analysis.py:9) and the FFT twiddle
  * tables (computed in float64, rounded to float32).  Replaces Analyzer.__init__ (analysis.py:6-14). */

@@ -163,3 +163,45 @@ def test_cli_and_worker_dispatch(tmp_path, fake_worker, capsys, monkeypatch):
     assert (tmp_path / "frames.rgb").read_bytes() == _expected(53, 16)
     assert json.loads(capsys.readouterr().out.strip().splitlines()[-1]) == {"type": "done"}
     assert sharded.main(["sharded", str(tmp_path / "missing.json"), "--gpus", "2"]) == 2
+
+
+def test_numa_placement_helpers(tmp_path):
+    """sharding.bind_near_device: reads the GPU's NUMA node and local CPUs from sysfs (a stand-in tree here), binds only to
+    CPUs the process may use, and leaves a host that hides its topology alone."""
+    import os
+    from aurora_amd import sharding
+    assert sharding.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert sharding.parse_cpulist("") == set()
+    dev = tmp_path / "0000:c1:00.0"
+    dev.mkdir()
+    (dev / "numa_node").write_text("1\n")
+    allowed = sorted(os.sched_getaffinity(0))
+    (dev / "local_cpulist").write_text(f"{allowed[0]}\n")
+    assert sharding.device_numa("0000:C1:00.0", str(tmp_path)) == (1, {allowed[0]})
+    assert sharding.device_numa("0000:ff:00.0", str(tmp_path)) == (None, set())
+
+    class _Lib:
+        def __init__(self, bus):
+            self.bus = bus
+
+        def aur_device_pci_bus_id(self, device, buf, n):
+            if self.bus is None:
+                return -1
+            buf.value = self.bus
+            return 0
+
+    before = os.sched_getaffinity(0)
+    try:
+        info = sharding.bind_near_device(_Lib(b"0000:c1:00.0"), 3, str(tmp_path))
+        assert info == {"device": 3, "bus_id": "0000:c1:00.0", "numa_node": 1, "bound_cpus": 1}
+        assert os.sched_getaffinity(0) == {allowed[0]}
+    finally:
+        os.sched_setaffinity(0, before)
+    (dev / "numa_node").write_text("-1\n")                      # virtual machines
+    assert sharding.bind_near_device(_Lib(b"0000:c1:00.0"), 0, str(tmp_path))["bound_cpus"] == 0
+    assert os.sched_getaffinity(0) == before
+    assert sharding.bind_near_device(_Lib(None), 0, str(tmp_path))["bus_id"] is None
+    (dev / "numa_node").write_text("0\n")
+    (dev / "local_cpulist").write_text("100000-100003\n")       # CPUs this process may not use: nothing changes
+    assert sharding.bind_near_device(_Lib(b"0000:c1:00.0"), 0, str(tmp_path))["bound_cpus"] == 0
+    assert os.sched_getaffinity(0) == before

@@ -38,6 +38,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PCIE_PEAK_GBS = 63.0           # same guide: host link PCIe Gen5 x16, 63 GB/s
+PCIE_COPY_GBS = 57.1           # profiles/r02_d2h_probe.txt: a bare hipMemcpyAsync of one ring slot into pinned memory on this pool
 F64_ISSUE_NS = 2.18            # profiles/r01_f64_issue_probe.txt: ns per VALU wave-instruction per SIMD under this load
 
 
@@ -385,6 +386,7 @@ def main():
             "roofline": roof,
             "roofline_pcie": {"bound": "pcie", "achieved": round(link_gbs, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
                               "frac": round(link_gbs / PCIE_PEAK_GBS, 4), "bytes_per_frame": wire_bytes,
+                              "bare_copy_gbs": PCIE_COPY_GBS,
                               "note": "per GPU: every exported frame crosses the GPU's PCIe Gen5 x16 link once"},
             "roofline_stft": roof_stft,
             "device_fps": device_leg["device_fps"] if device_leg else None,

@@ -13,6 +13,10 @@
 // (at most 256) group boxes against it; regions without a hit -- almost all of a frame -- end there.  Each wave then
 // walks 8 x 8 pixel tiles, one pixel per lane, narrows the region's groups down to the tile's and scans their segments.
 #include "common.h"
+// A/B build knob of tools/glow_lesion.sh (where the kernel's time goes): 1 = no layer loop, 2 = one segment per group
+#ifndef GLOW_LESION
+#define GLOW_LESION 0
+#endif
 
 #include <math.h>
 
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void glow_kernel(GlowArgs A) {
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-                for (int j = 0; j < kGroup; ++j) {
+                for (int j = 0; j < (GLOW_LESION == 2 ? 1 : kGroup); ++j) {
                     double qx, qy;
                     const double dd = seg_dist2(strip + 5 * j, px, py, qx, qy);
                     const int si = s0 + j;
@@ -220,7 +224,12 @@ __global__ __launch_bounds__(256) void glow_kernel(GlowArgs A) {
         uint8_t* p = A.frames + (((long)f * A.H + y) * A.W + x) * 3;
         uint32_t r = p[0], g8 = p[1], b8 = p[2];
         const uint32_t r_in = r, g_in = g8, b_in = b8;
+#if GLOW_LESION == 1
+        r = (uint32_t)(d + na + nb) & 255u;
+        for (int k = 0; k < 0; ++k) {
+#else
         for (int k = 0; k < A.K; ++k) {
+#endif
             const uint32_t cv = rim_coverage(A.hw[k] - d, na, nb);
             if (cv == 0u) continue;
             const uint32_t c = pm[k];

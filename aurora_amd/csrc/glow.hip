@@ -13,7 +13,8 @@
 // (at most 256) group boxes against it; regions without a hit -- almost all of a frame -- end there.  Each wave then
 // walks 8 x 8 pixel tiles, one pixel per lane, narrows the region's groups down to the tile's and scans their segments.
 #include "common.h"
-// A/B build knob of tools/glow_lesion.sh (where the kernel's time goes): 1 = no layer loop, 2 = one segment per group
+// A/B build knob of tools/glow_lesion.sh (where the kernel's time goes): 1 = no layer loop, 2 = one segment per group,
+// 3 = region test only, 4 = empty kernel
 #ifndef GLOW_LESION
 #define GLOW_LESION 0
 #endif
@@ -81,18 +82,18 @@ __global__ __launch_bounds__(256) void glow_prepare_kernel(const double* __restr
 
 // Area of the unit pixel on the inner side of the stroke's rim (oracle: round_stroke_coverage), 0..255; a >= b are the
 // absolute components of the unit normal, largest first.
-__device__ __forceinline__ uint32_t rim_coverage(double s, double a, double b) {
+__device__ __forceinline__ uint32_t rim_coverage(double s, double a, double b, double inv_a, double inv_2ab) {
     if (s >= kReach) return 255u;
     if (s <= -kReach) return 0u;
     const double u = s + (a + b) / 2.0;
     double f;
     if (u <= 0.0) f = 0.0;
     else if (u >= a + b) f = 1.0;
-    else if (u < b) f = (u * u) / ((2.0 * a) * b);
-    else if (u <= a) f = (u - b / 2.0) / a;
+    else if (u < b) f = (u * u) * inv_2ab;
+    else if (u <= a) f = (u - b / 2.0) * inv_a;
     else {
         const double r = (a + b) - u;
-        f = 1.0 - (r * r) / ((2.0 * a) * b);
+        f = 1.0 - (r * r) * inv_2ab;
     }
     double c = floor(f * 256.0);
     if (!(c == c) || c > 1.0e300 || c < -1.0e300) c = 0.0;
@@ -111,19 +112,45 @@ __device__ __forceinline__ double seg_dist2(const double* __restrict__ sg, doubl
     return dx * dx + dy * dy;
 }
 
+// Minimum over the 64 lanes as DPP row operations (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror,
+// row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3; lane 63 holds the result).  Every lane must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_ones(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = umin32(v, dpp_ones<0xB1, 0xF>(v));
+    v = umin32(v, dpp_ones<0x4E, 0xF>(v));
+    v = umin32(v, dpp_ones<0x141, 0xF>(v));
+    v = umin32(v, dpp_ones<0x140, 0xF>(v));
+    v = umin32(v, dpp_ones<0x142, 0xA>(v));
+    v = umin32(v, dpp_ones<0x143, 0xC>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 template <int kGroup>
 __global__ __launch_bounds__(256) void glow_kernel(GlowArgs A) {
     __shared__ int s_cand[kMaxGroups];
+    __shared__ float4 s_box[kMaxGroups];       // boxes of the region's candidate groups, in s_cand order
     __shared__ int s_count[4];
     __shared__ double s_seg[4][kGroup * 5];
     const int f = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int rx0 = blockIdx.x * 64, ry0 = blockIdx.y * 64;
+#if GLOW_LESION == 4
+    if (A.W > 0) return;
+#endif
     const float4* boxes = A.boxes + (long)f * A.ngroups;
     // region test: pixel centres of the region span [rx0 + .5, rx0 + 63.5]
     bool hit = false;
+    float4 my_box = {0.0f, 0.0f, 0.0f, 0.0f};
     if ((int)threadIdx.x < A.ngroups) {
         const float4 bb = boxes[threadIdx.x];
+        my_box = bb;
         hit = bb.x <= (float)(rx0 + 64) && bb.z >= (float)rx0 && bb.y <= (float)(ry0 + 64) && bb.w >= (float)ry0;
     }
     const unsigned long long m = __ballot(hit);
@@ -135,13 +162,27 @@ __global__ __launch_bounds__(256) void glow_kernel(GlowArgs A) {
         total += s_count[w];
     }
     if (total == 0) return;                                        // nothing of the path reaches this region
-    if (hit) s_cand[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)threadIdx.x;
+#if GLOW_LESION == 3
+    if (A.W > 0) return;
+#endif
+    if (hit) {
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        s_cand[slot] = (int)threadIdx.x;
+        s_box[slot] = my_box;
+    }
     __syncthreads();
     const double* segs = A.segs + (long)f * A.nseg * 5;
     const uint32_t* pm = A.pm + (long)f * A.K;
     const double rmax = A.hw_max + kReach;
     // group boxes are grown by hw_max + 2 px; the true (ungrown) box is what bounds a group's distance from below
     const float grow = (float)(A.hw_max + 2.0);
+    // the first 64 candidate groups (all of them, in all but pathological regions) stay in registers for every tile
+    int g_first = 0;
+    float4 bb_first = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (lane < total) {
+        g_first = s_cand[lane];
+        bb_first = s_box[lane];
+    }
     for (int t = wave; t < 64; t += 4) {
         const int tx0 = rx0 + (t & 7) * 8, ty0 = ry0 + (t >> 3) * 8;
         if (tx0 >= A.W || ty0 >= A.H) continue;                    // wave-uniform
@@ -154,33 +195,33 @@ __global__ __launch_bounds__(256) void glow_kernel(GlowArgs A) {
         int best_si = 0x7fffffff;
         for (int c0 = 0; c0 < total; c0 += 64) {
             bool th = false;
-            int g = 0;
-            float gd = 3.0e38f;                                    // lower bound of the tile centre's distance to the group
-            float4 bb = {0.0f, 0.0f, 0.0f, 0.0f};
+            int g = g_first;
+            float gd = 0.0f;                                       // lower bound of the tile centre's distance to the group
+            float4 bb = bb_first;
             if (c0 + lane < total) {
-                g = s_cand[c0 + lane];
-                bb = boxes[g];
+                if (c0 > 0) {                                      // regions with more than 64 candidate groups: rare
+                    g = s_cand[c0 + lane];
+                    bb = s_box[c0 + lane];
+                }
                 th = bb.x <= (float)(tx0 + 8) && bb.z >= (float)tx0 && bb.y <= (float)(ty0 + 8) && bb.w >= (float)ty0;
                 const float cxf = (float)tx0 + 4.0f, cyf = (float)ty0 + 4.0f;
                 const float ddx = fmaxf(fmaxf(bb.x - cxf, cxf - bb.z), 0.0f), ddy = fmaxf(fmaxf(bb.y - cyf, cyf - bb.w), 0.0f);
-                gd = th ? ddx * ddx + ddy * ddy : 3.0e38f;
+                gd = ddx * ddx + ddy * ddy;
             }
-            unsigned long long tm = __ballot(th);
+            if (__ballot(th) == 0ull) continue;
             // nearest group first, so that the others can be skipped against a good bound; the order does not change the
-            // result: ties between segments go to the lower index explicitly
-            while (tm) {
-                float mn = gd;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
-                const unsigned long long pick = __ballot(th && gd == mn) & tm;
-                if (pick == 0ull) break;                               // cannot happen: some lane of tm holds the minimum
-                const int bit = __builtin_ctzll(pick);
-                tm &= ~(1ull << bit);
-                if (lane == bit) gd = 3.0e38f;
-                const int grp = __builtin_amdgcn_readfirstlane(__shfl(g, bit, 64));
+            // result: ties between segments go to the lower index explicitly.  The key is the distance (a float >= 0
+            // orders like its bit pattern) with the lane in its low six bits: one wave minimum names the group's lane.
+            uint32_t key = th ? ((__float_as_uint(gd) & 0xffffffc0u) | (uint32_t)lane) : 0xffffffffu;
+            for (;;) {
+                const uint32_t mn = wave_min_u32(key);
+                if (mn == 0xffffffffu) break;
+                const int bit = (int)(mn & 63u);
+                if (lane == bit) key = 0xffffffffu;
+                const int grp = __builtin_amdgcn_readlane(g, bit);
                 // this lane's lower bound on the distance to anything in the group (ungrown box, float32 rounded down)
-                const float bx0 = __shfl(bb.x, bit, 64) + grow, by0 = __shfl(bb.y, bit, 64) + grow;
-                const float bx1 = __shfl(bb.z, bit, 64) - grow, by1 = __shfl(bb.w, bit, 64) - grow;
+                const float bx0 = readlane_f(bb.x, bit) + grow, by0 = readlane_f(bb.y, bit) + grow;
+                const float bx1 = readlane_f(bb.z, bit) - grow, by1 = readlane_f(bb.w, bit) - grow;
                 const float ldx = fmaxf(fmaxf(bx0 - pxf, pxf - bx1), 0.0f), ldy = fmaxf(fmaxf(by0 - pyf, pyf - by1), 0.0f);
                 const float lb = (ldx * ldx + ldy * ldy) * 0.999f - 1.0e-3f;
                 if (__ballot((double)lb <= best) == 0ull) continue;   // no pixel of the tile can find a nearer point there
@@ -219,8 +260,12 @@ __global__ __launch_bounds__(256) void glow_kernel(GlowArgs A) {
         if (A.excl_b != nullptr && (A.excl_b[(A.excl_b_static ? 0L : (long)f * A.H * A.W32) + wi] & bitm)) continue;
         double bqx, bqy;
         (void)seg_dist2(segs + (long)best_si * 5, px, py, bqx, bqy);
-        const double nx = fabs((px - bqx) / d), ny = fabs((py - bqy) / d);
+        // one reciprocal per pixel for the normal, two for the rim formula: shared by every layer (oracle: inv_d, inv_a,
+        // inv_2ab -- the same operations in the same order)
+        const double inv_d = 1.0 / d;
+        const double nx = fabs((px - bqx) * inv_d), ny = fabs((py - bqy) * inv_d);
         const double na = fmax(nx, ny), nb = fmin(nx, ny);
+        const double inv_a = 1.0 / na, inv_2ab = 1.0 / ((2.0 * na) * nb);
         uint8_t* p = A.frames + (((long)f * A.H + y) * A.W + x) * 3;
         uint32_t r = p[0], g8 = p[1], b8 = p[2];
         const uint32_t r_in = r, g_in = g8, b_in = b8;
@@ -230,7 +275,7 @@ __global__ __launch_bounds__(256) void glow_kernel(GlowArgs A) {
 #else
         for (int k = 0; k < A.K; ++k) {
 #endif
-            const uint32_t cv = rim_coverage(A.hw[k] - d, na, nb);
+            const uint32_t cv = rim_coverage(A.hw[k] - d, na, nb, inv_a, inv_2ab);
             if (cv == 0u) continue;
             const uint32_t c = pm[k];
             uint32_t ar = r + (c & 255u), ag = g8 + ((c >> 8) & 255u), ab = b8 + ((c >> 16) & 255u);

@@ -610,15 +610,18 @@ def round_stroke_coverage(d2, qx, qy, half_width):
     with np.errstate(invalid="ignore", divide="ignore"):
         d = np.sqrt(d2)
         s = half_width - d
-        nx = np.abs((px - qx) / d)
-        ny = np.abs((py - qy) / d)
+        inv_d = 1.0 / d                     # one reciprocal per pixel, shared by both components and by every layer
+        nx = np.abs((px - qx) * inv_d)
+        ny = np.abs((py - qy) * inv_d)
         a = np.maximum(nx, ny)
         b = np.minimum(nx, ny)
+        inv_a = 1.0 / a
+        inv_2ab = 1.0 / ((2.0 * a) * b)
         u = s + (a + b) / 2.0
-        f_lo = (u * u) / ((2.0 * a) * b)
-        f_mid = (u - b / 2.0) / a
+        f_lo = (u * u) * inv_2ab
+        f_mid = (u - b / 2.0) * inv_a
         r = (a + b) - u
-        f_hi = 1.0 - (r * r) / ((2.0 * a) * b)
+        f_hi = 1.0 - (r * r) * inv_2ab
         f = np.where(u <= 0.0, 0.0, np.where(u >= a + b, 1.0, np.where(u < b, f_lo, np.where(u <= a, f_mid, f_hi))))
         c = np.floor(f * 256.0)
     c = np.where(np.isfinite(c), c, 0.0)

@@ -76,7 +76,23 @@ __device__ void accumulate_edge(long long x0, long long y0, long long x1, long l
         const long long ylo = right ? ya : yb, yhi = right ? yb : ya;      // y at the piece's left / right end
         long long ex_hi = (hi - 1) >> 8;
         if (ex_hi > (long long)bx0 + bw - 1) ex_hi = (long long)bx0 + bw - 1;   // cells right of the box change nothing
-        for (long long ex = lo >> 8; ex <= ex_hi; ++ex) {
+        long long ex_lo = lo >> 8;
+        if (ex_lo < bx0) {
+            // the cells left of the box all add to cover[row][0], and their shares telescope (a cell's right crossing is
+            // the next cell's left crossing, same formula): one step to the box's left edge, however far out the edge starts
+            const long long edge = (long long)bx0 << 8;
+            const long long xcut = hi < edge ? hi : edge;
+            long long pyb;
+            if (xcut == hi) pyb = yhi;
+            else {
+                pyb = yl_x + floordiv_pos((xcut - xl) * (yr_x - yl_x), xr - xl);
+                pyb = pyb < ya ? ya : (pyb > yb ? yb : pyb);
+            }
+            atomicAdd(crow, sign * (int)(right ? (pyb - ylo) : (ylo - pyb)));
+            if (xcut == hi) continue;
+            ex_lo = bx0;
+        }
+        for (long long ex = ex_lo; ex <= ex_hi; ++ex) {
             const long long cxa = lo > (ex << 8) ? lo : (ex << 8);
             const long long cxb = hi < ((ex + 1) << 8) ? hi : ((ex + 1) << 8);
             long long pya, pyb;

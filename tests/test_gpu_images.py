@@ -53,7 +53,8 @@ def test_aa_coverage_bit_exact(eng, size):
     polys = [_envelope_like(W, H, 1), _envelope_like(W, H, 2, wavy=0.6),
              np.array([[10.5, 10.25], [W - 20.5, 10.25], [W - 20.5, H - 15.0], [10.5, H - 15.0]]),
              np.array([[W / 2, 3.1], [W / 2 + 40.3, H - 4.2], [W / 2 - 37.9, H - 9.6]]),
-             np.array([[-30.0, -20.0], [W + 25.0, H / 2.0], [-10.0, H + 40.0]])]          # reaches outside the frame
+             np.array([[-30.0, -20.0], [W + 25.0, H / 2.0], [-10.0, H + 40.0]]),          # reaches outside the frame
+             np.array([[-2500.0, H / 3.0], [W / 2.0, 5.5], [W + 1800.0, H - 7.25], [W / 3.0, H - 3.0]])]   # far outside
     for k, V in enumerate(polys):
         got, full = _coverage(eng, V, W, H)
         want = R.coverage_aa(V, W, H)

@@ -15,6 +15,8 @@ from __future__ import annotations
 import ctypes as C
 from dataclasses import dataclass
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -585,7 +587,12 @@ class HipExportEngine:
         (`set_center_image` returns False and the disc keeps its plain fill, rt_widget.py:226-242)."""
         if not path:
             return None
-        key = ("center_image", str(path))
+        try:                                       # a file rewritten under the same name is another image
+            st = os.stat(path)
+            stamp = (st.st_mtime_ns, st.st_size)
+        except OSError:
+            stamp = None
+        key = ("center_image", str(path), stamp)
         if key not in self._tables:
             from .images import load_image_rgba, premultiply_argb
             try:

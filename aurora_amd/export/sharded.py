@@ -251,6 +251,13 @@ def export_sharded(cfg: dict, world: int, progress_cb=None, worker_cmd=None, dev
             children.append(_Child(c, tmp, f"shard{r:03d}", worker_cmd or default_worker_cmd(), on_progress))
         failures = _run_children(children)
     if failures:
+        if not keep_segments:                      # no half-written segments left behind
+            for c in children_cfg:
+                seg = c["hip_raw_out"] if cfg.get("hip_raw_out") else c["out_path"]
+                try:
+                    os.remove(seg)
+                except OSError:
+                    pass
         raise RuntimeError("sharded export failed:\n" + "\n".join(failures))
     if cfg.get("hip_raw_out"):
         segs = [c["hip_raw_out"] for c in children_cfg]

@@ -135,6 +135,7 @@ def test_a_failing_shard_stops_the_others(tmp_path, fake_worker):
         sharded.export_sharded(cfg, 3, None, worker_cmd=fake_worker, devices=[0])
     assert "boom on rank 1" in str(ei.value)
     assert not (tmp_path / "frames.rgb").exists()
+    assert not list(tmp_path.glob("frames.seg*.rgb"))                   # rank 0 finished its segment: not left behind
 
 
 def test_many_tracks_are_dealt_over_gpu_lanes(tmp_path, fake_worker):

@@ -752,13 +752,34 @@ struct PaintSink {
 };
 
 constexpr int kPaintLanes = 8;
+// Blocks [0, stroke_blocks) of a frame paint the stroke; the blocks behind them paint the disc pixels of the rows pass 1
+// could not describe by one interval (kRowMulti), one lane per row: a lane returns at once for every other row -- all
+// rows of the discs an export produces.  Stroke pixels leave the disc's pixels out, so the two parts touch disjoint
+// pixels and need no order between them.
 __global__ __launch_bounds__(256) void paint_stroke_closed_kernel(const double* __restrict__ verts, int nv, int W, int H,
                                                                   int W32, const uint32_t* __restrict__ rows,
                                                                   const uint32_t* __restrict__ disc, int disc_static,
-                                                                  const uint32_t* __restrict__ pen_rgb,
+                                                                  const uint32_t* __restrict__ pen_rgb, int stroke_blocks,
                                                                   uint8_t* __restrict__ frames) {
     const int f = blockIdx.y;
     const long fr = disc_static ? 0 : f;
+    if ((int)blockIdx.x >= stroke_blocks) {
+        const int row = ((int)blockIdx.x - stroke_blocks) * 256 + threadIdx.x;
+        if (row >= H || rows[fr * H + row] != kRowMulti) return;
+        const uint32_t* src = disc + (fr * H + row) * W32;
+        uint8_t* dst = frames + ((long)f * H + row) * (long)W * 3;
+        for (int w = 0; w < W32; ++w) {
+            uint32_t bits = src[w];
+            while (bits) {
+                const int x = 32 * w + __builtin_ctz(bits);
+                bits &= bits - 1u;
+                dst[3 * x] = (uint8_t)kDisc24;
+                dst[3 * x + 1] = (uint8_t)(kDisc24 >> 8);
+                dst[3 * x + 2] = (uint8_t)(kDisc24 >> 16);
+            }
+        }
+        return;
+    }
     const PaintSink sink = {frames + (long)f * H * W * 3, rows + fr * H, disc + fr * H * W32, W, W32,
                             pen_rgb[f] & 0x00ffffffu};
     // kPaintLanes lanes per primitive, each taking every kPaintLanes-th of its pixel rows: the walk over a primitive's rows
@@ -766,32 +787,6 @@ __global__ __launch_bounds__(256) void paint_stroke_closed_kernel(const double* 
     const int t = blockIdx.x * 256 + threadIdx.x;
     stroke_primitive(verts + (long)f * nv * 2, nv, t / kPaintLanes, H, 1.0, 0.0, 0.0, 1, 0, sink, t % kPaintLanes,
                      kPaintLanes);
-}
-
-// Disc pixels of the rows pass 1 could not describe by one interval (kRowMulti).  One lane per (frame, row): it returns at
-// once for every other row -- all rows of the discs an export produces, so the launch costs a few microseconds -- and walks
-// the row's plane words itself otherwise.
-__global__ __launch_bounds__(256) void paint_disc_multi_rows_kernel(const uint32_t* __restrict__ rows,
-                                                                    const uint32_t* __restrict__ disc, int disc_static,
-                                                                    int W, int H, int W32, int n_frames,
-                                                                    uint8_t* __restrict__ frames) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_frames * H) return;
-    const int f = i / H, row = i - f * H;
-    const long fr = disc_static ? 0 : f;
-    if (rows[fr * H + row] != kRowMulti) return;
-    const uint32_t* src = disc + (fr * H + row) * W32;
-    uint8_t* dst = frames + ((long)f * H + row) * (long)W * 3;
-    for (int w = 0; w < W32; ++w) {
-        uint32_t bits = src[w];
-        while (bits) {
-            const int x = 32 * w + __builtin_ctz(bits);
-            bits &= bits - 1u;
-            dst[3 * x] = (uint8_t)kDisc24;
-            dst[3 * x + 1] = (uint8_t)(kDisc24 >> 8);
-            dst[3 * x + 2] = (uint8_t)(kDisc24 >> 16);
-        }
-    }
 }
 
 template <bool BASE>
@@ -1576,9 +1571,23 @@ extern "C" int aur_raster_planes(aur_ctx* ctx, const uint32_t* d_stroke_plane, c
 // A batch of closed-path frames without a stroke plane: pass 1 of aur_raster_planes, then the stroke painted straight into
 // the frames.  For renders that need no stroke plane afterwards (no fill / shadow / glow decoration).  Same frames as
 // aur_mask_stroke_closed + aur_raster_planes, bit for bit.
+extern "C" int aur_disc_rows(aur_ctx* ctx, const uint32_t* d_disc_plane, int n_planes, int W, int H, uint32_t* d_rows,
+                             void* stream) {
+    int rc = aur_use_device(ctx);
+    if (rc) return rc;
+    AUR_REQUIRE(n_planes >= 0 && n_planes <= 65535, "aur_disc_rows: n_planes %d outside [0, 65535]", n_planes);
+    AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_disc_rows: frame size %dx%d unsupported", W, H);
+    if (n_planes == 0) return AUR_OK;
+    AUR_REQUIRE(d_disc_plane && d_rows, "aur_disc_rows: null device pointer");
+    hipLaunchKernelGGL(disc_rows_kernel, dim3((H + 3) / 4, n_planes), dim3(256), 0, (hipStream_t)stream, d_disc_plane, H,
+                       (W + 31) / 32, d_rows);
+    AUR_CHECK_HIP(hipGetLastError());
+    return AUR_OK;
+}
+
 extern "C" int aur_raster_closed_path(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
-                                      const uint32_t* d_disc_plane, int disc_static, const uint8_t* d_pen_rgb,
-                                      uint8_t* d_frames, void* stream) {
+                                      const uint32_t* d_disc_plane, int disc_static, const uint32_t* d_disc_rows,
+                                      const uint8_t* d_pen_rgb, uint8_t* d_frames, void* stream) {
     int rc = aur_use_device(ctx);
     if (rc) return rc;
     if ((rc = check_plane_args("aur_raster_closed_path", n_frames, n_vertices, W, H))) return rc;
@@ -1589,17 +1598,22 @@ extern "C" int aur_raster_closed_path(aur_ctx* ctx, const double* d_verts, int n
     const int W32 = (W + 31) / 32, nu4 = W * 3 / 16;
     const long upf_l = (long)nu4 * H;
     const int table_frames = disc_static ? 1 : n_frames;
-    const bool ok = W % 32 == 0 && ((uintptr_t)d_frames & 15u) == 0 && ctx->fill_mode != 1 && ctx->d_rows != nullptr &&
+    const bool ok = W % 32 == 0 && ((uintptr_t)d_frames & 15u) == 0 && ctx->fill_mode != 1 &&
                     upf_l >= 256 && upf_l < (1L << 26) && (long)n_frames * upf_l + 256 < (1L << 31) &&
-                    (size_t)table_frames * H * 4 <= (size_t)AUR_ROWS_BYTES;
+                    (d_disc_rows != nullptr ||
+                     (ctx->d_rows != nullptr && (size_t)table_frames * H * 4 <= (size_t)AUR_ROWS_BYTES));
     if (!ok) {
         aur_set_error("aur_raster_closed_path: %dx%d frames (or this batch) are outside the linear fill's shapes; use "
                       "aur_mask_stroke_closed + aur_raster_planes", W, H);
         return AUR_EUNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
-    uint32_t* rows = reinterpret_cast<uint32_t*>(ctx->d_rows);
-    hipLaunchKernelGGL(disc_rows_kernel, dim3((H + 3) / 4, table_frames), dim3(256), 0, st, d_disc_plane, H, W32, rows);
+    const uint32_t* rows = d_disc_rows;
+    if (rows == nullptr) {                       // no table from the caller: built here, in the context's own table
+        uint32_t* mine = reinterpret_cast<uint32_t*>(ctx->d_rows);
+        hipLaunchKernelGGL(disc_rows_kernel, dim3((H + 3) / 4, table_frames), dim3(256), 0, st, d_disc_plane, H, W32, mine);
+        rows = mine;
+    }
     const int upf = (int)upf_l;
     const int head = (int)(((uintptr_t)d_frames & 4095u) / 16u);
     const unsigned total = (unsigned)n_frames * (unsigned)upf;
@@ -1611,11 +1625,10 @@ extern "C" int aur_raster_closed_path(aur_ctx* ctx, const double* d_verts, int n
     else
         hipLaunchKernelGGL(raster_fill_rows_kernel<false>, dim3(gfill), dim3(256), 0, st, rows, disc_static ? 1 : 0, H, nu4,
                            upf, 1.0f / (float)upf, 1.0f / (float)nu4, head, total, base, reinterpret_cast<uint4*>(d_frames));
-    hipLaunchKernelGGL(paint_stroke_closed_kernel, dim3((2 * n_vertices * kPaintLanes + 255) / 256, n_frames), dim3(256), 0, st, d_verts,
+    const int stroke_blocks = (2 * n_vertices * kPaintLanes + 255) / 256, multi_blocks = (H + 255) / 256;
+    hipLaunchKernelGGL(paint_stroke_closed_kernel, dim3(stroke_blocks + multi_blocks, n_frames), dim3(256), 0, st, d_verts,
                        n_vertices, W, H, W32, rows, d_disc_plane, disc_static ? 1 : 0,
-                       reinterpret_cast<const uint32_t*>(d_pen_rgb), d_frames);
-    hipLaunchKernelGGL(paint_disc_multi_rows_kernel, dim3((n_frames * H + 255) / 256), dim3(256), 0, st, rows,
-                       d_disc_plane, disc_static ? 1 : 0, W, H, W32, n_frames, d_frames);
+                       reinterpret_cast<const uint32_t*>(d_pen_rgb), stroke_blocks, d_frames);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

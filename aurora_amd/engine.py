@@ -847,7 +847,8 @@ class HipExportEngine:
             self.disc_composite(env, True, 1, W, H, box, frames=probe, source=white, full_plane=full)
             ce = probe[0, :, :, 0].reshape(-1)
             idx = torch.nonzero((ce > 0) & (ce < 255)).reshape(-1)
-            entry = dict(env=env, box=box, full=full, edge_index=idx.to(torch.int32).contiguous(),
+            entry = dict(env=env, box=box, full=full, rows=self.disc_rows(full, W, H),
+                         edge_index=idx.to(torch.int32).contiguous(),
                          edge_cov=ce[idx].contiguous(), placement=None, scaled=None)
             if prep.image is not None:
                 ih, iw = int(prep.image.shape[0]), int(prep.image.shape[1])
@@ -925,6 +926,13 @@ class HipExportEngine:
             self._tables[key] = self.torch.zeros((1, H, (W + 31) // 32), dtype=self.torch.int32, device=self.device)
         return self._tables[key]
 
+    def _no_disc_rows(self, W: int, H: int):
+        """Row table of the empty disc plane: every row empty."""
+        key = ("nodisc_rows", H)
+        if key not in self._tables:
+            self._tables[key] = self.torch.zeros((1, H), dtype=self.torch.int32, device=self.device)
+        return self._tables[key]
+
     def fill_planes(self, planes, pen_rgb, W: int, H: int, out=None):
         stroke, disc, static = planes
         count = int(stroke.shape[0])
@@ -941,17 +949,25 @@ class HipExportEngine:
             ev.append((e0, e1, count))
         return out
 
-    def raster_closed_path(self, verts, disc, static, pen_rgb, W: int, H: int, out):
+    def disc_rows(self, disc, W: int, H: int):
+        """Row table uint32 [n, H] of disc planes int32 [n, H, W32] (aur_disc_rows)."""
+        rows = self.empty((int(disc.shape[0]), H), self.torch.int32)
+        _lib.check(self.lib.aur_disc_rows(self.ctx.handle, _ptr(disc), int(disc.shape[0]), W, H, _ptr(rows),
+                                          self.stream()), "aur_disc_rows")
+        return rows
+
+    def raster_closed_path(self, verts, disc, static, pen_rgb, W: int, H: int, out, rows=None):
         """Closed-path frames without a stroke plane (aur_raster_closed_path): background / disc rows, then the stroke
-        painted straight into the frames."""
+        painted straight into the frames.  ``rows``: the disc's row table when the caller keeps one (a disc that does
+        not change from batch to batch), else it is built inside the call."""
         count = int(verts.shape[0])
         ev = self.fill_events
         if ev is not None:
             e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
             e0.record()
         _lib.check(self.lib.aur_raster_closed_path(self.ctx.handle, _ptr(verts), int(verts.shape[1]), count, W, H,
-                                                   _ptr(disc), int(static), _ptr(pen_rgb), _ptr(out), self.stream()),
-                   "aur_raster_closed_path")
+                                                   _ptr(disc), int(static), _ptr(rows), _ptr(pen_rgb), _ptr(out),
+                                                   self.stream()), "aur_raster_closed_path")
         if ev is not None:
             e1.record()
             ev.append((e0, e1, count))
@@ -976,10 +992,13 @@ class HipExportEngine:
         if out is None:
             out = self.empty((count, H, W, 3), self.torch.uint8)
         if self._direct_stroke_ok(W, out, want_fill or want_shadow or want_glow):
-            disc = (self._static_disc(prep, an, sc, W, H, first)["full"]
-                    if (prep.cfg.disc_static and prep.image is None) else self._no_disc_plane(W, H))
+            if prep.cfg.disc_static and prep.image is None:
+                sd = self._static_disc(prep, an, sc, W, H, first)
+                disc, rows = sd["full"], sd["rows"]          # the disc does not change: its row table is built once
+            else:
+                disc, rows = self._no_disc_plane(W, H), self._no_disc_rows(W, H)
             self.raster_closed_path(self.radial_path_vertices(prep, sc, W, H, first, count), disc, True,
-                                    sc.pen_rgb[first:first + count], W, H, out)
+                                    sc.pen_rgb[first:first + count], W, H, out, rows=rows)
             planes = None
         else:
             planes = self.radial_planes(prep, an, sc, W, H, first, count, planes_out)
@@ -1073,7 +1092,8 @@ class HipExportEngine:
             out = self.empty((count, H, W, 3), self.torch.uint8)
         if self._direct_stroke_ok(W, out, want_fill or want_shadow or want_glow):
             self.raster_closed_path(self.wave_circular_vertices(an, sc, W, H, first, count, rotation_deg),
-                                    self._no_disc_plane(W, H), True, sc.pen_rgb[first:first + count], W, H, out)
+                                    self._no_disc_plane(W, H), True, sc.pen_rgb[first:first + count], W, H, out,
+                                    rows=self._no_disc_rows(W, H))
             return out
         planes = self.wave_circular_planes(an, sc, W, H, first, count, rotation_deg, planes_out)
         self.fill_planes(planes, sc.pen_rgb[first:first + count], W, H, out)

@@ -408,10 +408,17 @@ int aur_set_background(aur_ctx* ctx, const uint8_t* d_base, int W, int H);
  * shadow / glow decoration): pass 1 of aur_raster_planes (background or base frame, disc rows), then the width-2 BevelJoin
  * stroke of d_verts painted straight into the frames in the pen colour, leaving out what the disc covers.  The same frames
  * as aur_mask_stroke_closed + aur_raster_planes, bit for bit, without the plane clear, the stroke plane and the patch pass.
- * Widths that are multiples of 32 and 16-byte aligned batches only: AUR_EUNSUPPORTED otherwise (use the two calls). */
+ * Widths that are multiples of 32 and 16-byte aligned batches only: AUR_EUNSUPPORTED otherwise (use the two calls).
+ * d_disc_rows: NULL, or the row table of d_disc_plane from aur_disc_rows (uint32 [1 or F][H]): a caller whose disc does
+ * not change from batch to batch -- the export default -- builds it once instead of once per call. */
 int aur_raster_closed_path(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
-                           const uint32_t* d_disc_plane, int disc_static, const uint8_t* d_pen_rgb, uint8_t* d_frames,
-                           void* stream);
+                           const uint32_t* d_disc_plane, int disc_static, const uint32_t* d_disc_rows,
+                           const uint8_t* d_pen_rgb, uint8_t* d_frames, void* stream);
+
+/* Row table of disc planes uint32 [n_planes][H][W32]: per row the pixel interval x0 | x1 << 16 the disc covers, 0 for an
+ * empty row, 0xffffffff for a row whose disc is not one interval (its pixels are then painted from the plane itself).
+ * What pass 1 of the closed-path fill reads instead of the plane (4 bytes per row). */
+int aur_disc_rows(aur_ctx* ctx, const uint32_t* d_disc_plane, int n_planes, int W, int H, uint32_t* d_rows, void* stream);
 
 /* ---- wire format ------------------------------------------------------------------------------- */
 

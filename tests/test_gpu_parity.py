@@ -1213,3 +1213,18 @@ def test_closed_path_entry_with_irregular_discs(eng, disc_kind):
     eng.raster_closed_path(verts, d_disc, nd == 1, pen, W, H, got)
     assert np.array_equal(_np(got), want), int(np.sum(_np(got) != want))
     assert (want == np.asarray(R.DISC_RGB, np.uint8)).all(axis=3).sum() > 0
+    # the same with the row table built by the caller (aur_disc_rows): one interval per row, 0 = empty, ~0 = several
+    rows = eng.disc_rows(d_disc, W, H)
+    t = _np(rows).view(np.uint32)
+    for f in range(nd):
+        for r in (0, H // 2, H - 1):
+            xs = np.nonzero(disc[f, r])[0]
+            if len(xs) == 0:
+                assert t[f, r] == 0
+            elif len(xs) == xs[-1] - xs[0] + 1:
+                assert t[f, r] == (xs[0] | ((xs[-1] + 1) << 16))
+            else:
+                assert t[f, r] == 0xFFFFFFFF
+    got2 = torch.full((F, H, W, 3), 0xA5, dtype=torch.uint8, device=eng.device)
+    eng.raster_closed_path(verts, d_disc, nd == 1, pen, W, H, got2, rows=rows)
+    assert np.array_equal(_np(got2), want)

@@ -751,7 +751,10 @@ struct PaintSink {
     }
 };
 
-constexpr int kPaintLanes = 8;
+#ifndef AUR_PAINT_LANES
+#define AUR_PAINT_LANES 8          // A/B build knob: lanes that share one stroke primitive
+#endif
+constexpr int kPaintLanes = AUR_PAINT_LANES;
 // Blocks [0, stroke_blocks) of a frame paint the stroke; the blocks behind them paint the disc pixels of the rows pass 1
 // could not describe by one interval (kRowMulti), one lane per row: a lane returns at once for every other row -- all
 // rows of the discs an export produces.  Stroke pixels leave the disc's pixels out, so the two parts touch disjoint

@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--mode", default="Spectrum - Linear")
+    ap.add_argument("--signal", default="pink", choices=("pink", "sweep"),
+                    help="synthetic track: pink noise (BASELINE.json configs[1..4]) or the 20 Hz - 20 kHz sine sweep (configs[0])")
     ap.add_argument("--glow", action="store_true", help="closed-path modes: add the glow decoration (7 additive strokes)")
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per raster launch / ring slot (0 = as many as fit the 1.6 GB of 64 4K frames: small "
@@ -80,8 +82,9 @@ def _cpu_export(job):
     from aurora_amd import synth
     from oracle import analysis_ref as A      # checker / baseline only
     from oracle import raster_ref as R
-    mode, sr, fps, W, H, frames, seed = job
-    audio = synth.pink(int(frames * sr / fps), 2, seed=seed)
+    mode, sr, fps, W, H, frames, seed, signal = job
+    n = int(frames * sr / fps)
+    audio = synth.sweep(n, sr, 2) if signal == "sweep" else synth.pink(n, 2, seed=seed)
     sunk = 0
     t0 = time.perf_counter()
     ref = A.analyze_track(audio, sr, fps)
@@ -97,7 +100,7 @@ def _cpu_export(job):
 def cpu_baseline(args):
     import multiprocessing as mp
     sr, fps, W, H = args.sample_rate, args.fps, args.width, args.height
-    F, dt = _cpu_export((args.mode, sr, fps, W, H, args.cpu_frames, 1234))
+    F, dt = _cpu_export((args.mode, sr, fps, W, H, args.cpu_frames, 1234, args.signal))
     out = {"value": round(F / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": f"first {F} frames ({F / fps:.1f} s of audio) of the same workload: numpy oracle analysis + software "
                      f"rasteriser + ascontiguousarray/tobytes into a null sink, {dt:.1f} s on 1 core (the reference "
@@ -109,7 +112,7 @@ def cpu_baseline(args):
         ctx = mp.get_context("spawn")                            # this process has initialised the GPU: never fork it
         t0 = time.perf_counter()
         with ctx.Pool(procs) as pool:
-            res = pool.map(_cpu_export, [(args.mode, sr, fps, W, H, per, 1234 + 7 * k) for k in range(procs)])
+            res = pool.map(_cpu_export, [(args.mode, sr, fps, W, H, per, 1234 + 7 * k, args.signal) for k in range(procs)])
         wall = time.perf_counter() - t0
         busy = max(r[1] for r in res)
         out["all_cores"] = {"value": round(sum(r[0] for r in res) / busy, 2), "unit": "frames/s", "cores": procs,
@@ -185,7 +188,12 @@ def main():
 
     # ------------------------------------------------------------------ headline: export into the host sink
     n_samples = int(round(args.seconds * sr))
-    audio = synth.pink_device(n_samples, 2, 1234 + rank, device)      # input resident in HBM before timing
+    def make_audio(n):
+        if args.signal == "sweep":
+            return synth.sweep_device(n, sr, 2, device)
+        return synth.pink_device(n, 2, 1234 + rank, device)
+
+    audio = make_audio(n_samples)                                     # input resident in HBM before timing
     track = eng.make_track(audio, sr, fps)
     F = track.total_frames
     stft_bytes = 4 * track.channels * min(track.hop, 1024) + 4 * 1025 + 8
@@ -248,7 +256,7 @@ def main():
     roof_stft = None
     if args.device_steps > 0:
         dn = int(round(args.device_seconds * sr))
-        daudio = synth.pink_device(dn, 2, 1234 + rank, device)
+        daudio = make_audio(dn)
         dtrack = eng.make_track(daudio, sr, fps)
         DF = dtrack.total_frames
         radial = RadialConfig() if kind == "spectrum_radial" else None
@@ -377,7 +385,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 FFT / f32 magnitudes / u8 RGB24",
             "data": "synthetic",
-            "config": {"workload": f"{args.seconds:.0f} s {sr} Hz stereo pink-noise track per GPU (resident in HBM), "
+            "config": {"workload": f"{args.seconds:.0f} s {sr} Hz stereo {'sine-sweep' if args.signal == 'sweep' else 'pink-noise'} track per GPU "
+                                   f"(resident in HBM), "
                                    f"{args.mode}{' + glow' if args.glow else ''} {W}x{H}@{fps}, {F} frames per GPU per "
                                    f"step, every frame read back through a pinned ring into a null sink ({args.wire})",
                        "frames_per_gpu": F, "batch_frames": B, "ring_slots": args.slots, "wire_format": args.wire,

@@ -104,6 +104,48 @@ def test_frames_vs_oracle_own_spectrum(eng, track4min, pool, mode, size):
     assert rate <= MAX_RATE[mode], rate
 
 
+def test_config0_sweep_every_frame(eng, pool):
+    """BASELINE.json configs[0] in full: the 30 s 44.1 kHz stereo sine sweep, "Spectrum - Linear" 1280x720@30, every one
+    of its 900 frames against the oracle's export of the oracle's own analysis.  The sweep is the hard input for the
+    spectrum: most bins of a frame are leakage, decades under the tone."""
+    import torch
+    from _frame_compare_worker import compare_frame
+    from aurora_amd import synth
+    sr, fps, W, H = 44100, 30, 1280, 720
+    audio = synth.sweep(sr * 30, sr, 2)
+    track = eng.upload_track(audio, sr, fps)
+    an = eng.analyze(track, want_samples=True)
+    sc = eng.scan(an)
+    ref = A.analyze_track(audio, sr, fps)
+    pen, _ = A.amp_to_color_track(ref["energy"])
+    F = track.total_frames
+    assert F == 900 and np.array_equal(sc.pen_rgb.cpu().numpy()[:, :3], pen)
+    got = an.logspec.cpu().numpy()
+    assert np.allclose(got, ref["logspec"], rtol=1e-4, atol=2e-6)           # the north star's spectrum tolerance
+    fb = W * H * 3
+    n_batch = 60
+    shm = shared_memory.SharedMemory(create=True, size=n_batch * fb)
+    try:
+        view = np.ndarray((n_batch, H, W, 3), dtype=np.uint8, buffer=shm.buf)
+        results = []
+        for b0 in range(0, F, n_batch):
+            n = min(n_batch, F - b0)
+            view[:n] = eng.render("Spectrum - Linear", an, sc, W, H, b0, n).cpu().numpy()
+            tasks = [(shm.name, j * fb, "Spectrum - Linear", ref["samples"][b0 + j], ref["logspec"][b0 + j],
+                      float(ref["energy"][b0 + j]), pen[b0 + j], W, H) for j in range(n)]
+            results.extend(pool.map(compare_frame, tasks))
+        del view
+    finally:
+        shm.close()
+        shm.unlink()
+    ndiff = np.array([r[0] for r in results])
+    ps = np.array([r[2] for r in results])
+    flipped = int(np.count_nonzero(ndiff))
+    print(f"\nconfigs[0] sweep 1280x720@30: {flipped} of {F} frames differ from the oracle's own export; worst frame "
+          f"{int(ndiff.max())} pixels, min PSNR {ps.min():.1f} dB")
+    assert ps.min() >= 50.0 and flipped <= 4 and ndiff.max() <= 8
+
+
 @pytest.mark.parametrize("mode,size,n_sampled", [("Spectrum - Radial", (1920, 1080), 480),
                                                  ("Spectrum - Radial", (3840, 2160), 240),
                                                  ("Waveform - Circular", (3840, 2160), 480)])

@@ -23,7 +23,7 @@ SYMBOLS = (
     "aur_spans_spectrum_linear", "aur_spans_particles", "aur_spans_waveform_linear", "aur_raster_spans",
     "aur_raster_work_bytes", "aur_span_summary", "aur_raster_spans_ws", "aur_raster_spans_static",
     "aur_radial_stage1", "aur_radial_ema", "aur_radial_vertices", "aur_envelope_vertices",
-    "aur_feather_ring_vertices", "aur_blend_planes", "aur_add_planes", "aur_multiply_plane", "aur_plane_exclude", "aur_wave_circular_vertices", "aur_mask_stroke_closed", "aur_mask_stroke_path", "aur_wave_linear_vertices", "aur_mask_polygon", "aur_raster_planes", "aur_raster_closed_path", "aur_disc_rows",
+    "aur_feather_ring_vertices", "aur_blend_planes", "aur_blend_planes_box", "aur_mask_polygon_box", "aur_add_planes", "aur_multiply_plane", "aur_plane_exclude", "aur_wave_circular_vertices", "aur_mask_stroke_closed", "aur_mask_stroke_path", "aur_wave_linear_vertices", "aur_mask_polygon", "aur_raster_planes", "aur_raster_closed_path", "aur_disc_rows",
     "aur_rgb24_to_yuv420p", "aur_raster_spans_yuv420p", "aur_rgb24_to_nv12", "aur_raster_spans_nv12",
     "aur_glow_work_bytes", "aur_glow_path",
     "aur_image_scale", "aur_center_image_placement", "aur_disc_composite", "aur_blend_pixels", "aur_compose_background", "aur_set_background",
@@ -134,6 +134,7 @@ def _declare(lib):
     lib.aur_feather_ring_vertices.argtypes = [vp, vp, vp, vp, i32, C.POINTER(EnvelopeParams), vp, i32, i32, vp, vp]
     lib.aur_plane_exclude.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]
     lib.aur_blend_planes.argtypes = [vp, vp, i32, C.c_char_p, i32, i32, i32, vp, vp]
+    lib.aur_blend_planes_box.argtypes = [vp, vp, i32, C.c_char_p, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.aur_multiply_plane.argtypes = [vp, vp, C.c_char_p, i32, i32, i32, vp, vp]
     lib.aur_add_planes.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.aur_wave_circular_vertices.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp, vp]
@@ -145,6 +146,7 @@ def _declare(lib):
     lib.aur_mask_stroke_path.argtypes = [vp, vp, i32, i32, i32, i32, C.c_double, C.c_double, C.c_double, i32, i32, vp, vp]
     lib.aur_wave_linear_vertices.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.aur_mask_polygon.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.aur_mask_polygon_box.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.aur_raster_planes.argtypes = [vp, vp, vp, i32, vp, i32, i32, i32, vp, vp]
     lib.aur_raster_closed_path.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp]
     lib.aur_disc_rows.argtypes = [vp, vp, i32, i32, i32, vp, vp]

@@ -489,14 +489,17 @@ __global__ __launch_bounds__(256) void mask_stroke_closed_kernel(const double* _
 // crossings (only NaN vertices produce them) drop their right-most crossing, as the sorted-pair rule of the oracle does.
 // The block then writes its rows as one contiguous piece of the plane; every word is written, so the plane needs no
 // clearing.
-__device__ __forceinline__ int span_edge(double x, int W) {
+__device__ __forceinline__ int span_edge(double x, int bx0, int W) {     // column relative to bx0, clamped to [0, W]
     const double a = fmin(fmax(x, -kBig), kBig);
-    const int c = (int)ceil(a - 0.5);
-    return c < 0 ? 0 : (c > W ? W : c);
+    const long c = (long)ceil(a - 0.5) - bx0;
+    return c < 0 ? 0 : (c > W ? W : (int)c);
 }
 constexpr int kPolyWords = 8192;     // LDS bitmap of a block: rows_per_block * W32 <= this (32 KB)
+// The plane may cover only a box of the frame (aur_mask_polygon_box): pixel columns [bx0, bx0 + W), rows [by0, by0 + H),
+// bx0 a multiple of 32; W, H, W32 are then the box's.  Crossings are computed in frame coordinates -- the arithmetic of the
+// full-frame plane, bit for bit -- and only the resulting pixel column and row are moved into the box.
 __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restrict__ verts, int nv, int W, int H,
-                                                           int W32, int rows_per_block, int vec_ok,
+                                                           int W32, int bx0, int by0, int rows_per_block, int vec_ok,
                                                            uint32_t* __restrict__ planes) {
     __shared__ uint32_t s_bits[kPolyWords];      // [row][word]: toggles, then the filled words
     __shared__ uint8_t s_par[kPolyWords];        // parity of the toggles of a word, then the carry into it
@@ -525,14 +528,14 @@ __global__ __launch_bounds__(128) void mask_polygon_kernel(const double* __restr
         ya = fmin(fmax(ya, -kBig), kBig);
         yb = fmin(fmax(yb, -kBig), kBig);
         long ra = (long)ceil(ya - 0.5) - 1, rb = (long)ceil(yb - 0.5);
-        if (ra < base) ra = base;
-        if (rb > base + rows_here - 1) rb = base + rows_here - 1;
+        if (ra < (long)by0 + base) ra = (long)by0 + base;
+        if (rb > (long)by0 + base + rows_here - 1) rb = (long)by0 + base + rows_here - 1;
         for (long r = ra; r <= rb; ++r) {
             const double yc = (double)r + 0.5;
             if ((y0 <= yc) != (y1 <= yc)) {
                 const double x = x0 + ((yc - y0) * (x1 - x0)) / (y1 - y0);
-                const int c = span_edge(x, W);                       // first pixel whose centre is at or right of x
-                const int rr = (int)(r - base);
+                const int c = span_edge(x, bx0, W);                  // first pixel whose centre is at or right of x
+                const int rr = (int)(r - by0 - base);
                 atomicAdd(&s_cnt[rr], 1);
                 atomicMax(&s_max[rr], c);
                 if (c < W) atomicXor(&s_bits[rr * W32 + (c >> 5)], 1u << (c & 31));
@@ -1134,13 +1137,16 @@ __device__ __forceinline__ void quarter_rmw(uint32_t any, const Op& op, int W, i
 }
 
 template <bool VEC, int KT>
+// Hp, W32p, xw0, y0: the planes may cover only a box of the frame (aur_blend_planes_box): Hp rows of W32p words whose first
+// word is word xw0 of frame row y0.
 __global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __restrict__ planes, int K, BlendColours col,
-                                                           int W, int H, int W32, uint8_t* __restrict__ frames) {
+                                                           int W, int H, int Hp, int W32p, int xw0, int y0,
+                                                           uint8_t* __restrict__ frames) {
     __shared__ uint32_t s_w[4][KT + 1][64];
     __shared__ uint8_t s_q[4][256];
     const int f = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int words = H * W32;
+    const int words = Hp * W32p;
     const int word0 = blockIdx.x * 256 + wave * 64;         // first word of this wave
     if (word0 >= words) return;                             // wave-uniform
     const int mine = (word0 + lane < words) ? word0 + lane : words - 1;
@@ -1182,23 +1188,25 @@ __global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __res
         const int src = id >> 2, q = id & 3;
         const uint32_t a8 = (s_w[wave][KT][src] >> (8 * q)) & 0xffu;
         const int word = word0 + src;
-        const int row = word / W32, w = word - row * W32;
+        const int row = word / W32p, w = word - row * W32p;
         uint32_t m[KT];
 #pragma unroll
         for (int k = 0; k < KT; ++k) m[k] = (s_w[wave][k][src] >> (8 * q)) & 0xffu;
-        const int x0 = w * 32 + q * 8;
+        const int x0 = (w + xw0) * 32 + q * 8;
         quarter_rmw<VEC>(a8, [&](int b, uint32_t& rb, uint32_t& g) { blend_pixel<KT>(m, b, col, rb, g); }, W, x0,
-                         frames + (((size_t)f * H + row) * W + x0) * 3);
+                         frames + (((size_t)f * H + (row + y0)) * W + x0) * 3);
     }
 }
 
 template <int KT>
 static void launch_blend(bool vec, dim3 grid, hipStream_t st, const uint32_t* planes, int K, const BlendColours& col,
-                         int W, int H, int W32, uint8_t* frames) {
+                         int W, int H, int Hp, int W32p, int xw0, int y0, uint8_t* frames) {
     if (vec)
-        hipLaunchKernelGGL((blend_planes_kernel<true, KT>), grid, dim3(256), 0, st, planes, K, col, W, H, W32, frames);
+        hipLaunchKernelGGL((blend_planes_kernel<true, KT>), grid, dim3(256), 0, st, planes, K, col, W, H, Hp, W32p, xw0, y0,
+                           frames);
     else
-        hipLaunchKernelGGL((blend_planes_kernel<false, KT>), grid, dim3(256), 0, st, planes, K, col, W, H, W32, frames);
+        hipLaunchKernelGGL((blend_planes_kernel<false, KT>), grid, dim3(256), 0, st, planes, K, col, W, H, Hp, W32p, xw0,
+                           y0, frames);
 }
 
 // ---- additive planes (glow) ----------------------------------------------------------------------------------------
@@ -1359,12 +1367,22 @@ extern "C" int aur_feather_ring_vertices(aur_ctx* ctx, const float* d_logspec, c
 
 extern "C" int aur_blend_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t* h_rgba, int n_frames,
                                int W, int H, uint8_t* d_frames, void* stream) {
+    return aur_blend_planes_box(ctx, d_planes, K, h_rgba, n_frames, W, H, 0, 0, W, H, d_frames, stream);
+}
+
+extern "C" int aur_blend_planes_box(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t* h_rgba, int n_frames,
+                                    int W, int H, int box_x, int box_y, int box_w, int box_h, uint8_t* d_frames,
+                                    void* stream) {
     int rc = aur_use_device(ctx);
     if (rc) return rc;
     AUR_REQUIRE(K >= 1 && K <= kBlendMaxK, "aur_blend_planes: K %d outside [1, %d]", K, kBlendMaxK);
     AUR_REQUIRE(n_frames >= 0 && n_frames <= 65535, "aur_blend_planes: n_frames %d outside [0, 65535]", n_frames);
     AUR_REQUIRE(W >= 16 && W <= 16384 && H >= 16 && H <= 16384, "aur_blend_planes: frame size %dx%d unsupported", W, H);
     AUR_REQUIRE(h_rgba != nullptr, "aur_blend_planes: null colour table");
+    AUR_REQUIRE(box_x >= 0 && box_y >= 0 && box_w >= 1 && box_h >= 1 && box_x + box_w <= ((W + 31) & ~31) &&
+                    box_y + box_h <= H && box_x % 32 == 0,
+                "aur_blend_planes_box: box %d,%d %dx%d outside the %dx%d frame or not on a 32-pixel column", box_x, box_y,
+                box_w, box_h, W, H);
     if (n_frames == 0) return AUR_OK;
     AUR_REQUIRE(d_planes && d_frames, "aur_blend_planes: null device pointer");
     BlendColours col = {};
@@ -1374,14 +1392,16 @@ extern "C" int aur_blend_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, c
         col.inv[k] = 255u - a;
         col.pm_rb[k] = col.pm[k][0] | (col.pm[k][2] << 16);
     }
-    const int W32 = (W + 31) / 32;
-    const dim3 grid((H * W32 + 255) / 256, n_frames);       // one lane per 32-pixel word
+    const int W32p = (box_w + 31) / 32, xw0 = box_x / 32;
+    const dim3 grid((box_h * W32p + 255) / 256, n_frames);  // one lane per 32-pixel word of the planes
     const bool vec = W % 8 == 0 && ((uintptr_t)d_frames & 7u) == 0;
     hipStream_t st = (hipStream_t)stream;
-    if (K == 1) launch_blend<1>(vec, grid, st, d_planes, K, col, W, H, W32, d_frames);          // fill, shadow
-    else if (K <= 6) launch_blend<6>(vec, grid, st, d_planes, K, col, W, H, W32, d_frames);     // feather rings
-    else if (K == 7) launch_blend<7>(vec, grid, st, d_planes, K, col, W, H, W32, d_frames);     // disc + rings
-    else launch_blend<kBlendMaxK>(vec, grid, st, d_planes, K, col, W, H, W32, d_frames);
+#define AUR_BLEND(KT) launch_blend<KT>(vec, grid, st, d_planes, K, col, W, H, box_h, W32p, xw0, box_y, d_frames)
+    if (K == 1) AUR_BLEND(1);                               // fill, shadow
+    else if (K <= 6) AUR_BLEND(6);                          // feather rings
+    else if (K == 7) AUR_BLEND(7);                          // disc + rings
+    else AUR_BLEND(kBlendMaxK);
+#undef AUR_BLEND
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }
@@ -1471,12 +1491,25 @@ extern "C" int aur_mask_stroke_path(aur_ctx* ctx, const double* d_verts, int n_v
 
 extern "C" int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
                                 uint32_t* d_plane, void* stream) {
+    return aur_mask_polygon_box(ctx, d_verts, n_vertices, n_frames, W, H, 0, 0, W, H, d_plane, stream);
+}
+
+extern "C" int aur_mask_polygon_box(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int frame_w,
+                                    int frame_h, int box_x, int box_y, int box_w, int box_h, uint32_t* d_plane,
+                                    void* stream) {
     int rc = aur_use_device(ctx);
     if (rc) return rc;
-    if ((rc = check_plane_args("aur_mask_polygon", n_frames, n_vertices, W, H))) return rc;
+    if ((rc = check_plane_args("aur_mask_polygon", n_frames, n_vertices, frame_w, frame_h))) return rc;
+    AUR_REQUIRE(box_x >= 0 && box_y >= 0 && box_w >= 1 && box_h >= 1 && box_x + box_w <= ((frame_w + 31) & ~31) &&
+                    box_y + box_h <= frame_h && box_x % 32 == 0,
+                "aur_mask_polygon_box: box %d,%d %dx%d outside the %dx%d frame or not on a 32-pixel column", box_x, box_y,
+                box_w, box_h, frame_w, frame_h);
     if (n_frames == 0) return AUR_OK;
     AUR_REQUIRE(d_verts && d_plane, "aur_mask_polygon: null device pointer");
-    const int W32 = (W + 31) / 32;
+    // the box's right edge never lies beyond the frame's: pixels past the last column stay 0
+    const int W = (box_x + box_w > frame_w) ? frame_w - box_x : box_w, H = box_h;
+    AUR_REQUIRE(W >= 1, "aur_mask_polygon_box: box starts past the last pixel column");
+    const int W32 = (box_w + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     // rows per block: as many as fit the block's LDS bitmap, at most one per thread; a multiple of 4 keeps the uint4
     // zero fill of empty blocks aligned
@@ -1484,8 +1517,9 @@ extern "C" int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_verti
     rpb = rpb > 128 ? 128 : rpb;
     rpb &= ~3;
     const int vec_ok = (W32 % 4 == 0 && ((uintptr_t)d_plane & 15u) == 0) ? 1 : 0;   // rows of empty blocks as uint4
+    rpb = rpb < 4 ? 4 : rpb;
     hipLaunchKernelGGL(mask_polygon_kernel, dim3((H + rpb - 1) / rpb, n_frames), dim3(128), 0, st, d_verts, n_vertices, W,
-                       H, W32, rpb, vec_ok, d_plane);
+                       H, W32, box_x, box_y, rpb, vec_ok, d_plane);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
 }

@@ -767,19 +767,44 @@ class HipExportEngine:
         """Blends the six translucent rings of frames first .. first + count into ``frames`` (in place).  with_disc:
         the centre disc (30, 30, 40) is composited first from its own plane (frames of a mode that has no disc)."""
         h, st = self.ctx.handle, self.stream()
-        W32 = (W + 31) // 32
         K = 7 if with_disc else 6
         step = 65535 // K
+        # planes of the box the disc and its rings stay in, not of the frame (a quarter of a 1080p frame)
+        bx, by, bw, bh = self.feather_box(prep.cfg, W, H)
+        rgba = (self.DISC_RGBA if with_disc else b"") + self.FEATHER_RGBA
         for off in range(0, count, step):
             n = min(step, count - off)
             rings = self.feather_ring_vertices(prep, an, sc, W, H, first + off, n)
             if with_disc:
                 env = self._envelope(prep, an, sc, W, H, first + off, n)
                 rings = self.torch.cat([env[:, None], rings], dim=1).contiguous()
-            planes = self.empty((n, K, H, W32), self.torch.int32)
-            _lib.check(self.lib.aur_mask_polygon(h, _ptr(rings), 361, K * n, W, H, _ptr(planes), st), "aur_mask_polygon")
-            self.blend_planes(planes, (self.DISC_RGBA if with_disc else b"") + self.FEATHER_RGBA, frames[off:off + n])
+            planes = self.empty((n, K, bh, (bw + 31) // 32), self.torch.int32)
+            _lib.check(self.lib.aur_mask_polygon_box(h, _ptr(rings), 361, K * n, W, H, bx, by, bw, bh, _ptr(planes), st),
+                       "aur_mask_polygon_box")
+            _lib.check(self.lib.aur_blend_planes_box(h, _ptr(planes), K, rgba, n, W, H, bx, by, bw, bh,
+                                                     _ptr(frames[off:off + n]), st), "aur_blend_planes_box")
         return frames
+
+    @staticmethod
+    def feather_box(cfg: RadialConfig, W: int, H: int):
+        """Pixel box (x, y, w, h; x a multiple of 32) that holds the envelope path and the six feather rings whatever the
+        audio does.  With m = min(w, h): the raw radius is at most inner + a, inner = 0.22 m, a = (0.025 waviness + 0.06
+        audio amount) m (|fbm|, |sin|, spec_norm and the energy factor are all <= 1; rt_widget.py:1021-1038); a ring
+        scales it by at most 1.09 (:1103); the envelope's soft limit maps g0 = a / (r_max - inner) to tanh(1.25 g0) /
+        tanh(1.25) <= min(1 / tanh(1.25), 1.25 g0 / tanh(1.25)) (:1040-1044)."""
+        m = float(min(W, H))
+        noise = cfg.edge_waviness / 100.0
+        audio = cfg.feather_audio_amount / 100.0 if cfg.feather_audio_enabled else 0.0
+        a = (0.025 * noise + 0.06 * audio) * m
+        ring = (0.22 * m + a) * 1.09
+        t = float(np.tanh(1.25))
+        env = 0.22 * m + min(0.26 * m / t, 1.25 * a / t)
+        r = max(ring, env) + 3.0
+        cx, cy = W / 2.0, H / 2.0
+        x0 = max(0, int(np.floor(cx - r))) & ~31
+        y0 = max(0, int(np.floor(cy - r)))
+        x1, y1 = min(W, int(np.ceil(cx + r)) + 1), min(H, int(np.ceil(cy + r)) + 1)
+        return x0, y0, x1 - x0, y1 - y0
 
     def _envelope(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int, count: int):
         cfg = prep.cfg

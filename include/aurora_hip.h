@@ -255,6 +255,12 @@ int aur_feather_ring_vertices(aur_ctx* ctx, const float* d_logspec, const double
                               double* d_rings, void* stream);
 int aur_blend_planes(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t* h_rgba /*[K][4]*/, int n_frames,
                      int W, int H, uint8_t* d_frames, void* stream);
+/* The same blend from planes that cover only a box of the frame: d_planes uint32 [n_frames, K, box_h, ceil(box_w/32)]
+ * holds pixel columns box_x .. box_x + box_w (box_x a multiple of 32) of rows box_y .. box_y + box_h.  The disc and its
+ * rings stay within 0.34 min(W, H) of the centre, a quarter of a 1080p frame: planes of the box are a quarter of the
+ * plane traffic.  Same pixels as aur_blend_planes on full planes, bit for bit. */
+int aur_blend_planes_box(aur_ctx* ctx, const uint32_t* d_planes, int K, const uint8_t* h_rgba /*[K][4]*/, int n_frames,
+                         int W, int H, int box_x, int box_y, int box_w, int box_h, uint8_t* d_frames, void* stream);
 
 /* "Waveform - Circular" (`_draw_waveform`, circular branch, rt_widget.py:871-896): the closed path through all
  * 1024 samples of a frame (segs = min(720, n), step = max(1, int(n / segs)) = 1),
@@ -277,6 +283,10 @@ int aur_mask_stroke_closed(aur_ctx* ctx, const double* d_verts, int n_vertices, 
                            uint32_t* d_plane, void* stream);
 int aur_mask_polygon(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H,
                      uint32_t* d_plane, void* stream);
+/* aur_mask_polygon into planes of a box of the frame (layout as aur_blend_planes_box): crossings are computed in frame
+ * coordinates, so the bits are those of the full-frame plane inside the box; what lies outside the box is not recorded. */
+int aur_mask_polygon_box(aur_ctx* ctx, const double* d_verts, int n_vertices, int n_frames, int W, int H, int box_x,
+                         int box_y, int box_w, int box_h, uint32_t* d_plane, void* stream);
 /* Stroke of half width `half_width` (pen width / 2) of the path translated by (dx, dy), closed or open:
  * `_draw_shadow_path` (rt_widget.py:579-594) strokes a path with a QPen of width max(2, shadow_blur), default
  * SquareCap / BevelJoin, after `p.translate(dist cos(angle), dist sin(angle))`; the radial / circular paths end with

@@ -1159,6 +1159,61 @@ def test_polygon_fill_with_hundreds_of_crossings_per_row(eng, size):
         assert np.array_equal(planes[0], want), int(np.count_nonzero(planes[0] != want))
 
 
+@pytest.mark.parametrize("size,box", [((640, 360), (192, 40, 300, 250)), ((1000, 562), (0, 0, 1000, 562)),
+                                      ((1000, 562), (320, 100, 680, 400)), ((352, 288), (64, 17, 97, 33))])
+def test_box_planes_equal_the_box_of_full_planes(eng, size, box):
+    """aur_mask_polygon_box / aur_blend_planes_box: planes of a box of the frame hold the bits the full-frame planes hold
+    inside it (polygons that start left of, above and below the box included), and blending them changes the same pixels
+    to the same values as the full planes with everything outside the box cleared."""
+    import ctypes as C
+    import torch
+    W, H = size
+    bx, by, bw, bh = box
+    rng = np.random.default_rng(W + bx)
+    K, n = 3, 5
+    a = 2.0 * np.pi * np.arange(n) / n
+    polys = np.empty((2, K, n, 2))
+    for f in range(2):
+        for k in range(K):
+            r = rng.uniform(0.2, 0.7) * min(W, H)
+            polys[f, k, :, 0] = W * rng.uniform(0.3, 0.7) + np.cos(a + k) * r * rng.uniform(0.4, 1.6, n)
+            polys[f, k, :, 1] = H * rng.uniform(0.3, 0.7) + np.sin(a + k) * r * rng.uniform(0.4, 1.6, n)
+    d_v = torch.from_numpy(polys).to(eng.device)
+    W32, bW32 = (W + 31) // 32, (bw + 31) // 32
+    full = torch.full((2, K, H, W32), -1, dtype=torch.int32, device=eng.device)
+    part = torch.full((2, K, bh, bW32), -1, dtype=torch.int32, device=eng.device)
+    h, st = eng.ctx.handle, eng.stream()
+    assert eng.lib.aur_mask_polygon(h, C.c_void_p(d_v.data_ptr()), n, 2 * K, W, H, C.c_void_p(full.data_ptr()), st) == 0
+    assert eng.lib.aur_mask_polygon_box(h, C.c_void_p(d_v.data_ptr()), n, 2 * K, W, H, bx, by, bw, bh,
+                                        C.c_void_p(part.data_ptr()), st) == 0, eng.lib.aur_last_error()
+    fb = R.unpack_mask(_np(full).view(np.uint32).reshape(2 * K * H, W32), W).reshape(2, K, H, W)
+    x1 = min(W, bx + bw)
+    pb = R.unpack_mask(_np(part).view(np.uint32).reshape(2 * K * bh, bW32), bW32 * 32).reshape(2, K, bh, bW32 * 32)
+    assert np.array_equal(pb[..., :x1 - bx], fb[:, :, by:by + bh, bx:x1])
+    assert not pb[..., x1 - bx:].any() and fb[:, :, by:by + bh, bx:x1].any()
+    # blend: full planes cleared outside the box against the box planes
+    inside = np.zeros((H, W), bool)
+    inside[by:by + bh, bx:x1] = True
+    padded = np.pad(fb & inside, ((0, 0), (0, 0), (0, 0), (0, W32 * 32 - W)))
+    cleared = np.ascontiguousarray(np.packbits(padded, axis=-1, bitorder="little")).view(np.uint32).reshape(2, K, H, W32)
+    d_cleared = torch.from_numpy(cleared.view(np.int32)).to(eng.device)
+    rgba = bytes([30, 30, 40, 255, 13, 13, 18, 60, 200, 10, 90, 128])
+    base = rng.integers(0, 256, size=(2, H, W, 3), dtype=np.uint8)
+    f_full = torch.from_numpy(base.copy()).to(eng.device)
+    f_box = torch.from_numpy(base.copy()).to(eng.device)
+    assert eng.lib.aur_blend_planes(h, C.c_void_p(d_cleared.data_ptr()), K, rgba, 2, W, H,
+                                    C.c_void_p(f_full.data_ptr()), st) == 0
+    assert eng.lib.aur_blend_planes_box(h, C.c_void_p(part.data_ptr()), K, rgba, 2, W, H, bx, by, bw, bh,
+                                        C.c_void_p(f_box.data_ptr()), st) == 0, eng.lib.aur_last_error()
+    assert np.array_equal(_np(f_box), _np(f_full))
+    assert (_np(f_box) != base).any() and np.array_equal(_np(f_box)[:, ~inside], base[:, ~inside])
+    # a box that is not on a 32-pixel column, or leaves the frame, is refused
+    assert eng.lib.aur_mask_polygon_box(h, C.c_void_p(d_v.data_ptr()), n, 2 * K, W, H, 16, 0, 64, 32,
+                                        C.c_void_p(part.data_ptr()), st) == -1
+    assert eng.lib.aur_blend_planes_box(h, C.c_void_p(part.data_ptr()), K, rgba, 2, W, H, 0, H - 8, 64, 32,
+                                        C.c_void_p(f_box.data_ptr()), st) == -1
+
+
 @pytest.mark.parametrize("mode", ["Spectrum - Radial", "Waveform - Circular"])
 @pytest.mark.parametrize("size", [(640, 360), (1280, 200), (352, 288)])
 def test_closed_path_without_a_stroke_plane(eng, mode, size):

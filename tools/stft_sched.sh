@@ -4,5 +4,5 @@
 cd "$(dirname "$0")/.."
 for v in 0 1 2 3 4 5 6; do
   echo "== v$v"
-  AURORA_HIP_LIB=$PWD/build_sched/lib_v$v.so timeout -k 10 100 python tools/stft_bench.py --reps 10 --check 2>&1 | grep -E "stft:|check" || exit 1
+  AURORA_HIP_LIB=$PWD/build_sched/lib_v$v.so timeout -k 10 100 python tools/stft_bench.py --reps 10 2>&1 | grep -E "stft:" || exit 1
 done

@@ -34,8 +34,10 @@ class Analyzer:
         self.buffer = np.zeros(self.fft_size, dtype=np.float32)
         self._d_buffer = self._eng.empty((self.fft_size,), torch.float32)
         self._d_prev_mag = self._eng.torch.zeros((_lib.NBINS,), dtype=torch.float32, device=self._eng.device)
-        self._d_logspec = self._eng.empty((_lib.NBINS,), torch.float32)
-        self._d_flux = self._eng.empty((1,), torch.float32)
+        # log-spectrum and flux sum share one device buffer: one readback per compute()
+        self._d_out = self._eng.empty((_lib.NBINS + 1,), torch.float32)
+        self._d_logspec = self._d_out[:_lib.NBINS]
+        self._d_flux = self._d_out[_lib.NBINS:]
 
     # prev_mag lives on the device; expose the reference attribute as a host copy
     @property
@@ -61,8 +63,9 @@ class Analyzer:
         torch = self._eng.torch
         self._d_buffer.copy_(torch.from_numpy(self.buffer))
         self._eng.stft_buffer(self._d_buffer, self._d_prev_mag, self._d_logspec, self._d_flux)
-        spec = self._d_logspec.cpu().numpy()                       # fresh float32[1025] per call
-        flux = float(self._d_flux.cpu().numpy()[0]) / (self.fft_size // 2 + 1)      # analysis.py:29
+        out = self._d_out.cpu().numpy()
+        spec = out[:_lib.NBINS].copy()                             # fresh float32[1025] per call
+        flux = float(out[_lib.NBINS]) / (self.fft_size // 2 + 1)   # analysis.py:29
         self.flux_smooth = self.flux_alpha * self.flux_smooth + (1 - self.flux_alpha) * flux   # analysis.py:30
         return spec, self.flux_smooth
 

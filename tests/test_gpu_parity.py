@@ -723,7 +723,7 @@ def test_feather_ring_vertices_vs_reference(eng):
     assert seen > 0 and worst <= 2e-3       # inherits the spectrum's last-ulp float32 difference through spec_norm
 
 
-@pytest.mark.parametrize("size", [(640, 368), (1280, 720)])
+@pytest.mark.parametrize("size", [(640, 368), (1280, 720), (1000, 562), (352, 640)])
 def test_feather_raster_bit_exact_given_same_vertices(eng, size):
     from aurora_amd import synth
     from aurora_amd.pipeline import FramePipeline

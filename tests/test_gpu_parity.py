@@ -954,6 +954,77 @@ def test_glow_decoration_raster_bit_exact(eng, mode, vs, size):
     assert lit > 1000 * an.n_frames
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_decoration_combinations(eng, seed):
+    """Randomised view states of the closed-path modes (fill with its three blends, path and envelope shadow, glow,
+    feather rings, wavy audio-reactive disc, mirror, rotation, smoothing amounts; widths of every fill path) against
+    the oracle's layer-by-layer composite in the reference's painting order."""
+    from aurora_amd import synth
+    from aurora_amd.engine import FillConfig, GlowConfig, ShadowConfig
+    from aurora_amd.pipeline import FramePipeline
+    rng = np.random.default_rng(1000 + seed)
+    pick = lambda *v: v[int(rng.integers(len(v)))]
+    mode = pick("Spectrum - Radial", "Spectrum - Radial", "Waveform - Circular")
+    W, H = pick((640, 368), (500, 282), (352, 288), (416, 240), (333, 200))
+    vs = dict(radial_rotation_deg=float(pick(0.0, 12.5, -40.0)))
+    if rng.random() < 0.6:
+        vs.update(radial_fill_enabled=True, radial_fill_threshold=float(pick(0.0, 0.05)),
+                  radial_fill_blend=pick("normal", "add", "multiply"),
+                  radial_fill_color=pick("#80FFFFFF", "#C0FF8040", "#6040C0FF"))
+    if rng.random() < 0.6:
+        vs.update(shadow_enabled=True, shadow_opacity=int(rng.integers(10, 100)), shadow_blur_radius=int(rng.integers(0, 9)),
+                  shadow_distance=int(rng.integers(0, 25)), shadow_angle_deg=int(rng.integers(-180, 180)))
+    if rng.random() < 0.6:
+        vs.update(glow_enabled=True, glow_radius=int(rng.integers(4, 40)), glow_strength=int(rng.integers(30, 101)),
+                  glow_color=pick("#80A0FFFF", "#FF40FF80", "#FFFF4060"))
+    if mode.endswith("Radial"):
+        vs.update(radial_mirror=bool(rng.integers(2)), radial_smooth_amount=int(pick(0, 50, 100)),
+                  radial_waveform_smoothness=int(pick(0, 50)), radial_temporal_smoothing=int(pick(0, 30, 90)),
+                  edge_waviness=int(pick(0, 0, 60)), feather_enabled=bool(rng.random() < 0.4),
+                  feather_audio_enabled=bool(rng.integers(2)), feather_audio_amount=int(rng.integers(0, 101)))
+    audio = synth.pink(2500, 2, seed=500 + seed) * float(pick(1.0, 3.0))
+    track = eng.upload_track(audio, 48000, 60)
+    fc, sh, gc = FillConfig.from_view_state(vs), ShadowConfig.from_view_state(vs), GlowConfig.from_view_state(vs)
+    radial = _radial_cfg(vs) if "Radial" in mode else None
+    pipe = FramePipeline(eng, track, mode, W, H, radial=radial, rotation_deg=vs["radial_rotation_deg"], fill=fc, shadow=sh,
+                         glow=gc)
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    energy, pen = _np(sc.energy), _np(sc.pen_rgb)[:, :3]
+    fill_rgb = R.fill_colour_over_background(fc.rgba, fc.blend) if fc.enabled else None
+    dx, dy = sh.offset
+    rings_all = None
+    if radial is not None:
+        verts, env = eng.radial_vertices(pipe._radial_prep, an, sc, W, H, 0, an.n_frames)
+        verts, env = _np(verts), _np(env)
+        if radial.feather_enabled:
+            rings_all = _np(eng.feather_ring_vertices(pipe._radial_prep, an, sc, W, H, 0, an.n_frames))
+    else:
+        verts, env = _np(eng.wave_circular_vertices(an, sc, W, H, 0, an.n_frames, vs["radial_rotation_deg"])), None
+    alphas = [max(10, 70 - 10 * k) for k in range(1, 7)]
+    for f in range(an.n_frames):
+        want = np.empty((H, W, 3), np.uint8)
+        want[:] = np.asarray(R.BG, np.uint8)
+        if fill_rgb is not None and energy[f] >= fc.threshold:
+            want[R.unpack_mask(R.polygon_mask(verts[f], W, H), W)] = np.asarray(fill_rgb, np.uint8)
+        if sh.active:
+            R.blend_solid(want, R.unpack_mask(R.stroke_mask_closed(verts[f], W, H, sh.half_width, dx, dy, True), W),
+                          (0, 0, 0), sh.alpha)
+        if gc.active:
+            R.apply_glow(want, verts[f], float(energy[f]), np.ones((H, W), bool), W, H, gc.rgba, gc.radius, gc.strength,
+                         gc.layers)
+        want[R.unpack_mask(R.stroke_mask_closed(verts[f], W, H), W)] = pen[f]
+        if env is not None:
+            if sh.active:
+                R.blend_solid(want, R.unpack_mask(R.stroke_mask_closed(env[f], W, H, sh.half_width, dx, dy, False), W),
+                              (0, 0, 0), sh.alpha)
+            R.draw_center_disc(want, env[f], W, H)
+        if rings_all is not None:
+            for rv, a in zip(rings_all[f], alphas):
+                R.blend_solid(want, R.unpack_mask(R.polygon_mask(rv, W, H), W), R.BG, a)
+        assert np.array_equal(frames[f], want), (seed, mode, (W, H), vs, f, int(np.sum(frames[f] != want)))
+
+
 def test_add_planes_saturation_and_odd_width(eng):
     """aur_add_planes alone: 16 layers of random planes and colours that saturate, a width that is no multiple of 8
     (byte path) and one that is (vector path), against numpy."""

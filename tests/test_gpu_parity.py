@@ -173,6 +173,41 @@ def test_raster_bit_exact_given_same_analysis(eng, mode, size):
         assert np.array_equal(frames[f], want), (mode, size, f, int(np.sum(frames[f] != want)))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_frame_sizes_every_mode(eng, seed):
+    """Random frame sizes (any width from the UI's minimum of 64 up, any height from 16: multiples of 32 / 16 / 4 and odd
+    ones take different fill kernels) for one random mode each, loud and quiet tracks, against the oracle."""
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    from oracle import radial_ref as RR
+    rng = np.random.default_rng(77 + seed)
+    mode = (MODES + ["Spectrum - Radial", "Waveform - Circular"])[seed % 5]
+    W = int(rng.integers(64, 901))
+    if rng.random() < 0.4:
+        W &= ~int(rng.choice([3, 15, 31]))
+    W = max(64, W)
+    H = int(rng.integers(16, 481))
+    sr, fps = (48000, 60) if seed % 2 else (44100, 30)
+    audio = synth.make("pink" if seed % 3 else "sweep", 5 * (sr // fps) + int(rng.integers(0, 700)), sr) * float(rng.choice([0.2, 1.0, 2.5]))
+    audio = audio.astype(np.float32)
+    track = eng.upload_track(audio, sr, fps)
+    pipe = FramePipeline(eng, track, mode, W, H)
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    ls, energy, pen = _np(an.logspec), _np(sc.energy), _np(sc.pen_rgb)[:, :3]
+    ref = A.analyze_track(audio, sr, fps)
+    assert frames.shape == (track.total_frames, H, W, 3)
+    for f in range(track.total_frames):
+        if mode == "Spectrum - Radial":
+            verts, env = eng.radial_vertices(pipe._radial_prep, an, sc, W, H, f, 1)
+            want = R.render_radial_frame(_np(verts)[0], _np(env)[0], pen[f], W, H)
+        elif mode == "Waveform - Circular":
+            want = R.render_wave_circular_frame(RR.wave_circular_path(ref["samples"][f], float(energy[f]), W, H), pen[f], W, H)
+        else:
+            want = R.render_frame(mode, ref["samples"][f], ls[f], float(energy[f]), pen[f], W, H)
+        assert np.array_equal(frames[f], want), (seed, mode, (W, H), f, int(np.sum(frames[f] != want)))
+
+
 @pytest.mark.parametrize("K", [2, 5])
 @pytest.mark.parametrize("size,offset16", [((1280, 720), 0), ((1920, 1080), 5), ((3840, 2160), 0), ((176, 32), 3),
                                            ((2048, 16), 255)])

@@ -82,6 +82,36 @@ def test_analysis_vs_reference_fixtures(eng, name):
     assert np.array_equal(bm[:, 0], ls[:, :80].max(axis=1)) and np.array_equal(bm[:, 1], ls[:, :50].max(axis=1))
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_rates_channels_and_lengths(eng, seed):
+    """Random sample rate, frame rate (hop from 66 to 8000 samples: shorter and longer than the 1024-sample block),
+    channel count (mono 1-D and 2-D, stereo, 3..8 channels) and ragged track length against the oracle: the exporter's
+    position map, zero-padded mono samples, energy, pen colour and phase bit-exact, spectra within the north star's bar."""
+    rng = np.random.default_rng(4242 + seed)
+    sr = int(rng.choice([8000, 11025, 22050, 32000, 44100, 48000, 96000]))
+    fps = int(rng.choice([12, 24, 25, 30, 50, 60, 120]))
+    ch = int(rng.choice([0, 1, 2, 2, 3, 5, 8]))                       # 0: a 1-D mono array
+    n = int(rng.integers(1, 14)) * (sr // fps) + int(rng.integers(0, sr // fps))
+    x = rng.standard_normal((n, max(1, ch))).astype(np.float32) * np.float32(rng.choice([0.05, 0.4, 1.5]))
+    if ch == 0:
+        x = x[:, 0]
+    sens = float(rng.choice([0.5, 1.0, 2.0]))
+    ref = A.analyze_track(x, sr, fps, sensitivity=sens)
+    pen, _ = A.amp_to_color_track(ref["energy"])
+    from aurora_amd import _lib
+    track = eng.upload_track(x, sr, fps)
+    assert track.hop == ref["hop"] and track.total_frames == ref["total_frames"] == len(ref["pos"])
+    assert np.array_equal(track.pos_host[:track.total_frames], ref["pos"])
+    an = eng.analyze(track, want_samples=True)
+    sc = eng.scan(an, _lib.ScanParams.defaults(sens))
+    assert np.array_equal(_np(an.samples), ref["samples"]), (sr, fps, ch, n)
+    assert np.array_equal(_np(sc.energy), ref["energy"]), (sr, fps, ch, n)
+    assert np.array_equal(_np(sc.pen_rgb)[:, :3], pen)
+    assert np.array_equal(_np(sc.phase), A.phase_track(ref["energy"]))
+    assert np.allclose(_np(an.logspec), ref["logspec"], rtol=RTOL, atol=ATOL), (sr, fps, ch, n)
+    assert np.allclose(_np(sc.flux_smooth), ref["flux_smooth"], rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("kind,sr,fps,n", [("pink", 48000, 60, 48000 * 4 + 321), ("sweep", 44100, 30, 44100 * 5),
                                            ("sweep", 48000, 60, 48000 * 3)])
 def test_spectrum_error_vs_fp64_truth(eng, kind, sr, fps, n):

@@ -196,6 +196,26 @@ def test_background_composition_bit_exact(eng, tmp_path, mode, off, dim, isize):
     assert np.array_equal(base, want), (mode, int(np.sum(base != want)))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_background_plans(eng, tmp_path, seed):
+    """Random frame size, image size (smaller and larger than the frame, extreme aspect ratios), scale mode, offsets and dim:
+    the composed base frame (plan + smooth scaling in all four axis combinations + source-over + dim) against the oracle."""
+    pytest.importorskip("PIL")
+    from aurora_amd.images import BackgroundConfig
+    rng = np.random.default_rng(900 + seed)
+    W, H = int(rng.integers(64, 400)), int(rng.integers(16, 260))
+    iw, ih = int(rng.integers(1, 500)), int(rng.integers(1, 400))
+    mode = ["fill", "fit", "stretch", "center", "tile"][seed % 5]
+    off = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+    dim = int(rng.choice([0, 0, 15, 60, 100]))
+    rgba = _test_image(iw, ih, seed, alpha=bool(rng.integers(2)))
+    path = str(tmp_path / "bg.png")
+    _write_png(path, rgba)
+    base = _np(eng.compose_background(BackgroundConfig(path, mode, off[0], off[1], dim), W, H))
+    want = R.compose_background(R.premultiply(rgba), W, H, mode, off, dim)
+    assert np.array_equal(base, want), (seed, (W, H), (iw, ih), mode, off, dim, int(np.sum(base != want)))
+
+
 @pytest.mark.parametrize("size", [(320, 192), (336, 190), (330, 190), (323, 191)])
 @pytest.mark.parametrize("mode", ["Spectrum - Linear", "Waveform - Linear", "Particles", "Spectrum - Radial",
                                   "Waveform - Circular"])

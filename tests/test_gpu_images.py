@@ -165,6 +165,41 @@ def test_radial_center_image_frames(eng, tmp_path, case):
     assert len({frames[f].tobytes() for f in range(an.n_frames)}) > 1
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_center_images(eng, tmp_path, seed):
+    """Random frame size, image size (tiny to larger than the frame), zoom, motion, disc waviness and rotation, with and
+    without an alpha channel: every frame against the oracle (antialiased clip x smooth-scaled image at the placement)."""
+    pytest.importorskip("PIL")
+    from aurora_amd import synth
+    from aurora_amd.engine import RadialConfig
+    from aurora_amd.pipeline import FramePipeline
+    rng = np.random.default_rng(300 + seed)
+    W, H = int(rng.integers(5, 12)) * 32 - int(rng.choice([0, 0, 7, 16])), int(rng.integers(100, 240))
+    iw, ih = int(rng.integers(2, 400)), int(rng.integers(2, 300))
+    rgba = _test_image(iw, ih, seed, alpha=bool(rng.integers(2)))
+    path = str(tmp_path / "centre.png")
+    _write_png(path, rgba)
+    vs = dict(center_image_path=path, center_image_zoom=int(rng.choice([25, 60, 100, 100, 170, 300])),
+              center_motion=int(rng.choice([0, 0, 30, 100])), radial_rotation_deg=float(rng.choice([0.0, 33.0])))
+    if rng.random() < 0.5:
+        vs.update(edge_waviness=int(rng.integers(1, 101)), feather_audio_enabled=True,
+                  feather_audio_amount=int(rng.integers(0, 101)))
+    cfg = RadialConfig.from_view_state(vs, 1.0)
+    track = eng.upload_track(synth.pink(2500, 2, seed=40 + seed) * float(rng.choice([0.5, 2.0])), 48000, 60)
+    pipe = FramePipeline(eng, track, "Spectrum - Radial", W, H, radial=cfg)
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    verts, env = eng.radial_vertices(pipe._radial_prep, an, sc, W, H, 0, an.n_frames)
+    verts, env, pen = _np(verts), _np(env), _np(sc.pen_rgb)[:, :3]
+    energy, phase = _np(sc.energy), _np(sc.phase)
+    pm = R.premultiply(rgba)
+    for f in range(an.n_frames):
+        pl = R.center_image_placement(env[f], iw, ih, cfg.center_image_zoom, cfg.center_motion, float(energy[f]),
+                                      float(phase[f]))
+        want = R.render_radial_frame(verts[f], env[f], pen[f], W, H, image_pm=pm, placement=pl)
+        assert np.array_equal(frames[f], want), (seed, (W, H), (iw, ih), vs, f, int(np.sum(frames[f] != want)))
+
+
 def test_radial_unreadable_center_image_keeps_the_fill(eng, tmp_path):
     from aurora_amd import synth
     from aurora_amd.engine import RadialConfig

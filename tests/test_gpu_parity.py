@@ -384,6 +384,52 @@ def test_pipeline_readback_and_shards_byte_identical(eng):
         assert seen and seen[-1][0] == seen[-1][1]
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_shard_cuts_batches_and_wire_formats(eng, seed):
+    """Any mode with random decorations, cut at random frames into 1-5 time shards, each shard streamed through the pinned
+    ring with its own batch size and slot count: the concatenation is the unsharded stream, byte for byte, in all three
+    wire formats (halo, carried scalar state, carried `_radial_prev`, per-shard decoration state)."""
+    import io
+    from aurora_amd import synth
+    from aurora_amd.engine import FillConfig, GlowConfig, ShadowConfig
+    from aurora_amd.pipeline import FramePipeline
+    rng = np.random.default_rng(8800 + seed)
+    mode = (MODES + ["Spectrum - Radial", "Waveform - Circular"])[seed % 5]
+    W, H = [(320, 192), (352, 200), (256, 144)][seed % 3]
+    wire = ["rgb24", "yuv420p", "nv12"][seed % 3]
+    vs = {}
+    if mode in ("Spectrum - Radial", "Waveform - Circular"):
+        if rng.random() < 0.5:
+            vs.update(radial_fill_enabled=True, radial_fill_threshold=0.05)
+        if rng.random() < 0.5:
+            vs.update(glow_enabled=True, glow_radius=12)
+        if rng.random() < 0.5:
+            vs.update(shadow_enabled=True)
+        vs.update(radial_temporal_smoothing=int(rng.choice([0, 30, 90])), feather_enabled=bool(rng.integers(2)),
+                  edge_waviness=int(rng.choice([0, 50])))
+    elif mode == "Waveform - Linear" and rng.random() < 0.5:
+        vs.update(shadow_enabled=True)
+    sr, fps = 48000, 60
+    track = eng.upload_track(synth.pink(sr // 2 + int(rng.integers(0, 900)), 2, seed=seed), sr, fps)
+    F = track.total_frames
+
+    def pipe(a, b, batch, slots):
+        return FramePipeline(eng, track, mode, W, H, frame_begin=a, frame_end=b, batch_frames=batch, slots=slots,
+                             radial=_radial_cfg(vs) if mode == "Spectrum - Radial" else None, wire_format=wire,
+                             fill=FillConfig.from_view_state(vs), shadow=ShadowConfig.from_view_state(vs),
+                             glow=GlowConfig.from_view_state(vs))
+
+    whole = io.BytesIO()
+    assert pipe(0, F, 64, 2).run(whole) == F
+    nshards = int(rng.integers(1, 6))
+    cuts = [0] + sorted(int(c) for c in rng.integers(0, F + 1, nshards - 1)) + [F]      # empty shards included
+    parts = io.BytesIO()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert pipe(a, b, int(rng.integers(1, 12)), int(rng.integers(1, 4))).run(parts) == b - a
+    assert parts.getvalue() == whole.getvalue(), (seed, mode, wire, vs, cuts)
+    assert len(whole.getvalue()) == F * (W * H * 3 if wire == "rgb24" else W * H * 3 // 2)
+
+
 def test_analyzer_dropin_matches_oracle(eng):
     from aurora_amd.audio.analysis import Analyzer
     rng = np.random.default_rng(0)

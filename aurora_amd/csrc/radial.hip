@@ -1066,6 +1066,10 @@ struct BlendColours {
     uint32_t pm[kBlendMaxK][3];      // premultiplied source div255(c a), per channel (computed on the host)
     uint32_t inv[kBlendMaxK];        // 255 - a
     uint32_t pm_rb[kBlendMaxK];      // pm[k][0] | pm[k][2] << 16
+    // Planes from the last opaque one on decide a pixel alone when all of them cover it (whatever lay there is
+    // overwritten, then blended over in a fixed sequence): that colour, as the three dwords of eight such pixels.
+    int last_opaque;                 // -1: no plane has alpha 255
+    uint32_t solid[3];
 };
 __host__ __device__ __forceinline__ uint32_t div255(uint32_t x) { return (x + (x >> 8) + 0x80u) >> 8; }
 
@@ -1193,6 +1197,20 @@ __global__ __launch_bounds__(256) void blend_planes_kernel(const uint32_t* __res
 #pragma unroll
         for (int k = 0; k < KT; ++k) m[k] = (s_w[wave][k][src] >> (8 * q)) & 0xffu;
         const int x0 = (w + xw0) * 32 + q * 8;
+        if (VEC && col.last_opaque >= 0 && x0 + 8 <= W) {
+            // the disc's interior: every plane from the opaque one on covers all eight pixels -- stores only
+            uint32_t all = 0xffu;
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+                if (k >= col.last_opaque && k < K) all &= m[k];
+            if (all == 0xffu) {
+                uint2* q2 = reinterpret_cast<uint2*>(frames + (((size_t)f * H + (row + y0)) * W + x0) * 3);
+                q2[0] = uint2{col.solid[0], col.solid[1]};
+                q2[1] = uint2{col.solid[2], col.solid[0]};
+                q2[2] = uint2{col.solid[1], col.solid[2]};
+                continue;
+            }
+        }
         quarter_rmw<VEC>(a8, [&](int b, uint32_t& rb, uint32_t& g) { blend_pixel<KT>(m, b, col, rb, g); }, W, x0,
                          frames + (((size_t)f * H + (row + y0)) * W + x0) * 3);
     }
@@ -1391,6 +1409,20 @@ extern "C" int aur_blend_planes_box(aur_ctx* ctx, const uint32_t* d_planes, int 
         for (int ch = 0; ch < 3; ++ch) col.pm[k][ch] = div255((uint32_t)h_rgba[4 * k + ch] * a);
         col.inv[k] = 255u - a;
         col.pm_rb[k] = col.pm[k][0] | (col.pm[k][2] << 16);
+    }
+    col.last_opaque = -1;
+    for (int k = 0; k < K; ++k)
+        if (col.inv[k] == 0u) col.last_opaque = k;
+    if (col.last_opaque >= 0) {
+        uint32_t c[3];
+        for (int ch = 0; ch < 3; ++ch) {
+            c[ch] = col.pm[col.last_opaque][ch];                     // alpha 255: d' = c
+            for (int k = col.last_opaque + 1; k < K; ++k) c[ch] = col.pm[k][ch] + div255(c[ch] * col.inv[k]);
+        }
+        const uint32_t r = c[0], g = c[1], b = c[2];
+        col.solid[0] = r | (g << 8) | (b << 16) | (r << 24);
+        col.solid[1] = g | (b << 8) | (r << 16) | (g << 24);
+        col.solid[2] = b | (r << 8) | (g << 16) | (b << 24);
     }
     const int W32p = (box_w + 31) / 32, xw0 = box_x / 32;
     const dim3 grid((box_h * W32p + 255) / 256, n_frames);  // one lane per 32-pixel word of the planes

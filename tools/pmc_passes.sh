@@ -6,14 +6,15 @@ tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # the device-side leg alone (no export leg: counter collection serialises the queues, the readback pipeline is left
 # out): one warm-up and one timed step over the 1 h unit
-BENCH="bench.py --seconds 4 --steps 0 --cpu-frames 0 --device-steps 1 --device-warmup 0 --batch 128"
+eval "EXTRA=(${BENCH_EXTRA:-})"     # e.g. BENCH_EXTRA='--mode "Spectrum - Radial" --device-seconds 120'
+BENCH=(bench.py --seconds 4 --steps 0 --cpu-frames 0 --device-steps 1 --device-warmup 0 --batch 128 "${EXTRA[@]}")
 out=gpurun_out/pmc_$tag
 mkdir -p $out
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o p -- python3 $BENCH > $out/fetch.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o p -- python3 "${BENCH[@]}" > $out/fetch.log 2>&1
 echo "fetch pass done"
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o p -- python3 $BENCH > $out/write.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o p -- python3 "${BENCH[@]}" > $out/write.log 2>&1
 echo "write pass done"
-timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY --output-format csv -d $out/sq -o p -- python3 $BENCH > $out/sq.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY --output-format csv -d $out/sq -o p -- python3 "${BENCH[@]}" > $out/sq.log 2>&1
 echo "sq pass done"
 python3 tools/pmc_summarize.py $out > $out/summary.txt
 cat $out/summary.txt

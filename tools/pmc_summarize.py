@@ -16,7 +16,8 @@ from collections import defaultdict
 def short(name):
     for key in ("stft_frames_kernel", "raster_fill_lin_kernel", "raster_fill16_kernel", "raster_fill_kernel",
                 "span_summary_kernel", "scan_frames_kernel", "spans_spectrum_kernel", "spans_waveform_kernel",
-                "spans_particles_kernel"):
+                "spans_particles_kernel", "raster_fill_rows_kernel", "paint_stroke_closed_kernel",
+                "raster_patch_planes_kernel", "glow_kernel"):
         if key in name:
             return key
     return None

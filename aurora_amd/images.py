@@ -40,19 +40,28 @@ def load_image_rgba(path: str) -> np.ndarray:
     if Image is not None:
         with Image.open(path) as im:
             return np.ascontiguousarray(np.asarray(im.convert("RGBA"), dtype=np.uint8))
-    ffmpeg = shutil.which("ffmpeg")
+    try:
+        from .export.exporter import _ffmpeg_bin
+        ffmpeg = _ffmpeg_bin()                     # AURORA_FFMPEG, IMAGEIO_FFMPEG_EXE, imageio_ffmpeg, PATH
+    except Exception:
+        ffmpeg = shutil.which("ffmpeg")
     if ffmpeg is None:
         raise RuntimeError("neither Pillow nor ffmpeg is available to decode " + path)
-    probe = subprocess.run([ffmpeg, "-v", "error", "-i", path, "-f", "rawvideo", "-pix_fmt", "rgba", "-frames:v", "1",
-                            "-vf", "showinfo", "-"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    if probe.returncode != 0:
-        raise RuntimeError(f"ffmpeg could not decode {path}: {probe.stderr.decode('utf-8', 'ignore')}")
+    # one decoded frame as raw rgba on stdout; the size is in FFmpeg's description of the input stream on stderr
+    # ("Stream #0:0: Video: png, rgba(pc), 640x480, ...") and must agree with the number of bytes that arrived
+    run = subprocess.run([ffmpeg, "-hide_banner", "-nostdin", "-i", path, "-f", "rawvideo", "-pix_fmt", "rgba",
+                          "-frames:v", "1", "-"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if run.returncode != 0:
+        raise RuntimeError(f"ffmpeg could not decode {path}: {run.stderr.decode('utf-8', 'ignore')[-2000:]}")
     import re
-    m = re.search(rb" s:(\d+)x(\d+)", probe.stderr)
-    if not m:
-        raise RuntimeError(f"ffmpeg did not report the size of {path}")
-    w, h = int(m.group(1)), int(m.group(2))
-    return np.frombuffer(probe.stdout[:w * h * 4], dtype=np.uint8).reshape(h, w, 4).copy()
+    for line in run.stderr.splitlines():
+        if b"Video:" not in line:
+            continue
+        for m in re.finditer(rb"(?<![\dx])(\d{1,5})x(\d{1,5})(?![\dx])", line):
+            w, h = int(m.group(1)), int(m.group(2))
+            if w > 0 and h > 0 and w * h * 4 == len(run.stdout):
+                return np.frombuffer(run.stdout, dtype=np.uint8).reshape(h, w, 4).copy()
+    raise RuntimeError(f"ffmpeg did not report a size that matches the {len(run.stdout)} decoded bytes of {path}")
 
 
 def qsize_scaled(w: int, h: int, tw: int, th: int, aspect: str):

@@ -626,3 +626,41 @@ def test_ffmpeg_pipe_is_grown():
         proc.stdin.close()
         proc.wait()
     assert _grow_pipe(object()) == 0                 # anything that is not a pipe: left alone
+
+
+def test_image_decode_falls_back_to_ffmpeg(tmp_path, monkeypatch):
+    """load_image_rgba without Pillow: one raw rgba frame from FFmpeg (a stand-in script here), its size taken from the
+    stream description on stderr and checked against the bytes that arrived; anything else is an error."""
+    import stat
+    import sys
+    from aurora_amd import images
+    rgba = (np.arange(7 * 5 * 4) % 251).astype(np.uint8).reshape(5, 7, 4)
+    raw = tmp_path / "frame.raw"
+    raw.write_bytes(rgba.tobytes())
+    ff = tmp_path / "ffmpeg"
+    ff.write_text(f"""#!{sys.executable}
+import sys
+a = sys.argv[1:]
+if "-encoders" in a:
+    sys.exit(0)
+src = a[a.index("-i") + 1]
+if src.endswith("bad.png"):
+    sys.stderr.write("bad.png: Invalid data found when processing input\\n"); sys.exit(1)
+sys.stderr.write("Input #0, png_pipe, from 'x.png':\\n  Duration: N/A, bitrate: N/A\\n"
+                 "  Stream #0:0: Video: png, rgba(pc, gbr/unknown/unknown), 7x5 [SAR 2835:2835 DAR 7:5], 25 fps\\n")
+assert a[a.index("-pix_fmt") + 1] == "rgba" and a[-1] == "-"
+sys.stdout.buffer.write(open({str(raw)!r}, "rb").read() if not src.endswith("short.png") else b"1234")
+""")
+    ff.chmod(ff.stat().st_mode | stat.S_IXUSR)
+    monkeypatch.setenv("AURORA_FFMPEG", str(ff))
+    monkeypatch.setitem(sys.modules, "PIL", None)                      # `from PIL import Image` raises ImportError
+    for name in ("x.png", "bad.png", "short.png"):
+        (tmp_path / name).write_bytes(b"not really a png")
+    got = images.load_image_rgba(str(tmp_path / "x.png"))
+    assert got.dtype == np.uint8 and np.array_equal(got, rgba)
+    with pytest.raises(RuntimeError, match="could not decode"):
+        images.load_image_rgba(str(tmp_path / "bad.png"))
+    with pytest.raises(RuntimeError, match="did not report a size"):
+        images.load_image_rgba(str(tmp_path / "short.png"))
+    with pytest.raises(FileNotFoundError):
+        images.load_image_rgba(str(tmp_path / "missing.png"))

@@ -130,14 +130,20 @@ class FillConfig:
 
     @staticmethod
     def parse_colour(text, fallback):
-        """QColor('#AARRGGBB' | '#RRGGBB'); an invalid string keeps the previous colour (rt_widget.py:369-372)."""
-        t = str(text).lstrip("#")
+        """QColor(str) for the '#' forms Qt accepts -- '#AARRGGBB' (what the UI writes: `name(QColor.HexArgb)`,
+        export/exporter.py:27), '#RRGGBB', '#RGB', '#RRRGGGBBB', '#RRRRGGGGBBBB' (the high byte of each channel) -- as
+        (r, g, b, a); anything else is an invalid QColor and keeps the previous colour (rt_widget.py:369-372)."""
+        t = str(text).strip()
+        if not t.startswith("#"):
+            return fallback
+        t = t[1:]
         try:
             if len(t) == 8:
                 a, r, g, b = (int(t[i:i + 2], 16) for i in (0, 2, 4, 6))
                 return (r, g, b, a)
-            if len(t) == 6:
-                r, g, b = (int(t[i:i + 2], 16) for i in (0, 2, 4))
+            if len(t) in (3, 6, 9, 12):
+                n = len(t) // 3
+                r, g, b = (int((t[i * n:(i + 1) * n] * 2)[:2], 16) for i in range(3))     # '#RGB': F -> FF
                 return (r, g, b, 255)
         except ValueError:
             pass

@@ -664,3 +664,20 @@ sys.stdout.buffer.write(open({str(raw)!r}, "rb").read() if not src.endswith("sho
         images.load_image_rgba(str(tmp_path / "short.png"))
     with pytest.raises(FileNotFoundError):
         images.load_image_rgba(str(tmp_path / "missing.png"))
+
+
+def test_colour_strings_as_qcolor_reads_them():
+    """view_state colours (`radial_fill_color`, `glow_color`): the '#' forms QColor accepts; anything else is an invalid
+    QColor, which the reference's setters ignore (rt_widget.py:369-372), i.e. the default stays."""
+    from aurora_amd.engine import FillConfig
+    fb = (1, 2, 3, 4)
+    assert FillConfig.parse_colour("#80FFFFFF", fb) == (255, 255, 255, 0x80)
+    assert FillConfig.parse_colour("#c0ff8040", fb) == (0xff, 0x80, 0x40, 0xc0)
+    assert FillConfig.parse_colour("#FF8040", fb) == (0xff, 0x80, 0x40, 255)
+    assert FillConfig.parse_colour("#F84", fb) == (0xff, 0x88, 0x44, 255)
+    assert FillConfig.parse_colour("#FFF888444", fb) == (0xff, 0x88, 0x44, 255)
+    assert FillConfig.parse_colour("#FFFF88884444", fb) == (0xff, 0x88, 0x44, 255)
+    for bad in ("", "#", "#12", "#GGHHII", "FF8040", "#12345", None, 17):
+        assert FillConfig.parse_colour(bad, fb) == fb
+    assert FillConfig.from_view_state({"radial_fill_color": "nonsense"}).rgba == (255, 255, 255, 48)   # rt_widget.py:102
+    assert FillConfig.from_view_state({"radial_fill_threshold": "x"}).threshold == 0.1

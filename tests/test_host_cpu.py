@@ -681,3 +681,30 @@ def test_colour_strings_as_qcolor_reads_them():
         assert FillConfig.parse_colour(bad, fb) == fb
     assert FillConfig.from_view_state({"radial_fill_color": "nonsense"}).rgba == (255, 255, 255, 48)   # rt_widget.py:102
     assert FillConfig.from_view_state({"radial_fill_threshold": "x"}).threshold == 0.1
+
+
+@pytest.mark.parametrize("width", [1, 2, 3, 4])
+def test_stdlib_wav_reader_agrees_with_the_scipy_path(tmp_path, width):
+    """The last-resort PCM reader (no soundfile, scipy refuses the file) scales 8 / 16 / 24 / 32-bit samples exactly as
+    the scipy path of load_audio does (libsndfile's float32 conversion: x / 2^(bits-1), 8-bit unsigned around 128)."""
+    import wave
+    from aurora_amd.export import exporter
+    rng = np.random.default_rng(width)
+    n, ch = 257, 2
+    if width == 1:
+        raw = rng.integers(0, 256, size=n * ch, dtype=np.uint8).tobytes()
+    else:
+        v = rng.integers(-(1 << (8 * width - 1)), 1 << (8 * width - 1), size=n * ch, dtype=np.int64)
+        v[:3] = [-(1 << (8 * width - 1)), (1 << (8 * width - 1)) - 1, 0]
+        raw = b"".join(int(x).to_bytes(width, "little", signed=True) for x in v)
+    path = str(tmp_path / f"pcm{8 * width}.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(ch)
+        w.setsampwidth(width)
+        w.setframerate(22050)
+        w.writeframes(raw)
+    a, sr = exporter._read_wav_stdlib(path)
+    b, sr2 = exporter.load_audio(path)
+    assert sr == sr2 == 22050 and a.shape == b.shape == (n, ch) and a.dtype == b.dtype == np.float32
+    assert np.array_equal(a, b)
+    assert -1.0 <= a.min() and a.max() <= 1.0          # 32-bit full scale rounds to 1.0 in float32

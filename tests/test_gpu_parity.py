@@ -430,6 +430,37 @@ def test_random_shard_cuts_batches_and_wire_formats(eng, seed):
     assert len(whole.getvalue()) == F * (W * H * 3 if wire == "rgb24" else W * H * 3 // 2)
 
 
+def test_pipeline_sink_failures_end_the_run(eng):
+    """A sink that stops reading (BrokenPipeError, FFmpeg gone: exporter.py:543-544 stops writing and lets the exit code
+    speak) ends the run quietly; any other error of the sink comes out of run(); neither leaves the producer waiting for a
+    ring slot, and the pipeline can run again afterwards."""
+    import io
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    W, H = 320, 192
+    track = eng.upload_track(synth.pink(48000, 2, seed=4), 48000, 60)
+
+    class Sink:
+        def __init__(self, fail_at, exc):
+            self.calls, self.fail_at, self.exc, self.bytes = 0, fail_at, exc, 0
+
+        def write(self, buf):
+            self.calls += 1
+            if self.calls >= self.fail_at:
+                raise self.exc
+            self.bytes += len(buf)
+
+    pipe = FramePipeline(eng, track, "Spectrum - Linear", W, H, batch_frames=5, slots=2)
+    broken = Sink(3, BrokenPipeError())
+    pipe.run(broken)                                                    # no exception
+    assert broken.bytes == 2 * 5 * W * H * 3
+    failing = Sink(2, OSError("disk full"))
+    with pytest.raises(OSError, match="disk full"):
+        pipe.run(failing)
+    buf = io.BytesIO()
+    assert pipe.run(buf) == track.total_frames and len(buf.getvalue()) == track.total_frames * W * H * 3
+
+
 def test_analyzer_dropin_matches_oracle(eng):
     from aurora_amd.audio.analysis import Analyzer
     rng = np.random.default_rng(0)

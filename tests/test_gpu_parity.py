@@ -461,6 +461,16 @@ def test_pipeline_sink_failures_end_the_run(eng):
     assert pipe.run(buf) == track.total_frames and len(buf.getvalue()) == track.total_frames * W * H * 3
 
 
+def test_device_sweep_matches_the_host_generator(eng):
+    """bench.py --signal sweep builds the sine sweep on the device: same signal as synth.sweep up to the device's sine."""
+    from aurora_amd import synth
+    n, sr = 44100 * 2 + 17, 44100
+    dev = synth.sweep_device(n, sr, 2, eng.device).cpu().numpy()
+    host = synth.sweep(n, sr, 2)
+    assert dev.shape == host.shape == (n, 2) and dev.dtype == np.float32
+    assert np.max(np.abs(dev - host)) < 1e-5 and abs(float(np.abs(dev).max()) - 0.8) < 1e-3
+
+
 def test_analyzer_dropin_matches_oracle(eng):
     from aurora_amd.audio.analysis import Analyzer
     rng = np.random.default_rng(0)

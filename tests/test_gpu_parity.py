@@ -471,6 +471,22 @@ def test_device_sweep_matches_the_host_generator(eng):
     assert np.max(np.abs(dev - host)) < 1e-5 and abs(float(np.abs(dev).max()) - 0.8) < 1e-3
 
 
+def test_stream_synchronize_and_version(eng):
+    """The two entry points the Python host side does not need itself (it waits on torch events): a C caller's way to wait
+    for a stream, and the ABI version."""
+    import torch
+    lib = eng.lib
+    assert lib.aur_version() == 1
+    side = torch.cuda.Stream(device=eng.device)
+    x = torch.zeros(1 << 20, device=eng.device)
+    with torch.cuda.stream(side):
+        x += 1.0
+    assert lib.aur_stream_synchronize(eng.ctx.handle, side.cuda_stream) == 0
+    assert side.query() and float(x[0]) == 1.0
+    assert lib.aur_stream_synchronize(eng.ctx.handle, None) == 0             # the default stream
+    assert lib.aur_stream_synchronize(None, None) != 0 and b"null" in lib.aur_last_error()
+
+
 def test_analyzer_dropin_matches_oracle(eng):
     from aurora_amd.audio.analysis import Analyzer
     rng = np.random.default_rng(0)

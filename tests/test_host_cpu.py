@@ -708,3 +708,33 @@ def test_stdlib_wav_reader_agrees_with_the_scipy_path(tmp_path, width):
     assert sr == sr2 == 22050 and a.shape == b.shape == (n, ch) and a.dtype == b.dtype == np.float32
     assert np.array_equal(a, b)
     assert -1.0 <= a.min() and a.max() <= 1.0          # 32-bit full scale rounds to 1.0 in float32
+
+
+def test_every_entry_point_rejects_a_null_context():
+    """No GPU needed: every entry point that takes a context returns an error code (and sets a message) for a null context
+    and null / zero arguments instead of touching them."""
+    import ctypes as C
+    lib = _lib.load()
+    free_standing = {"aur_version", "aur_last_error", "aur_device_count", "aur_create", "aur_destroy", "aur_host_alloc",
+                     "aur_host_free", "aur_raster_work_bytes", "aur_glow_work_bytes", "aur_device_pci_bus_id"}
+    checked = 0
+    for name in _lib.SYMBOLS:
+        if name in free_standing:
+            continue
+        fn = getattr(lib, name)
+        args = []
+        for t in fn.argtypes:
+            if t in (C.c_double, C.c_float):
+                args.append(0.0)
+            elif t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
+                args.append(None)
+            else:
+                args.append(0)
+        assert fn(*args) != 0, name
+        assert lib.aur_last_error(), name
+        checked += 1
+    assert checked >= 45
+    out = C.c_size_t(0)
+    assert lib.aur_raster_work_bytes(4, 3840, C.byref(out)) == 0 and out.value > 0
+    assert lib.aur_raster_work_bytes(4, 3840, None) != 0
+    assert lib.aur_host_alloc(None, 16) != 0 and lib.aur_host_free(None) == 0

@@ -37,6 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_WRITE_CEILING_GBS = 6900.0 # tools/write_ceiling.py / tools/fill_lab on this pool: what torch's fill_ / zero_ and a bare store kernel reach
 PCIE_PEAK_GBS = 63.0           # same guide: host link PCIe Gen5 x16, 63 GB/s
 PCIE_COPY_GBS = 57.1           # profiles/r02_d2h_probe.txt: a bare hipMemcpyAsync of one ring slot into pinned memory on this pool
 F64_ISSUE_NS = 2.18            # profiles/r01_f64_issue_probe.txt: ns per VALU wave-instruction per SIMD under this load
@@ -132,6 +133,7 @@ def kernel_stats(events, bytes_per_frame):
     gbs = frames * bytes_per_frame / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "write_ceiling_gbs": HBM_WRITE_CEILING_GBS, "frac_of_write_ceiling": round(gbs / HBM_WRITE_CEILING_GBS, 4),
             "avg_launch_ms": round(ms / launches, 4), "frames_per_launch": round(frames / launches, 1),
             "algorithmic_bytes_per_frame": bytes_per_frame}
 
@@ -323,6 +325,9 @@ def main():
         ddt = sharding.max_over_ranks(time.perf_counter() - t1, device if backend == "nccl" else None)
         roof_dev = kernel_stats(ev_f, frame_bytes)
         roof_stft = kernel_stats(ev_s, stft_bytes)
+        if roof_stft is not None:                      # a read-and-compute kernel: the store ceiling says nothing about it
+            roof_stft.pop("write_ceiling_gbs", None)
+            roof_stft.pop("frac_of_write_ceiling", None)
         # `roofline` is the fill kernel at steady clocks (back-to-back launches of the device leg).  Inside the export
         # steps the same launches are timed too (`fill_in_export_steps`): there the GPU idles ~98 % of the time waiting
         # for the PCIe link and its clocks ramp down between the 0.24 ms bursts, so the kernel runs slower without

@@ -140,6 +140,8 @@ def kernel_stats(events, bytes_per_frame):
 
 def main():
     args = parse_args()
+    # multi-process GPU work on this pool needs dmabuf IPC (already exported there; kept if the launcher dropped it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 

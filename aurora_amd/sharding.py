@@ -55,6 +55,67 @@ def gather_digests_in_order(digest: str, n_bytes: int, dst: int = 0):
     return out
 
 
+# ---- one process per GPU, started by a parent that never touches a GPU ---------------------------------------------
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def launch_ranks(world: int, argv, script: str, env=None, python: str | None = None, poll_s: float = 0.2) -> int:
+    """Starts ``world`` fresh child processes ``python script *argv`` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set (what ``torch.distributed.run`` would set for one node) and waits for them.  Rank 0 inherits this
+    process's stdout (its one JSON line is the job's); the other ranks' stdout goes to stderr.  A rank that fails takes
+    the others down with it (they would wait in a barrier for good otherwise).  Returns the worst exit status.
+
+    The caller must not have touched the GPU: children are started with ``subprocess`` (fork + exec of a new
+    interpreter), never by re-executing the running program."""
+    import subprocess
+    import sys
+    import time
+    world = int(world)
+    if world < 1:
+        raise ValueError(f"world {world}")
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("MASTER_PORT", str(free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base["WORLD_SIZE"] = base["LOCAL_WORLD_SIZE"] = str(world)
+    procs = []
+    try:
+        for r in range(world):
+            e = dict(base)
+            e["RANK"] = e["LOCAL_RANK"] = str(r)
+            procs.append(subprocess.Popen([python or sys.executable, script, *argv], env=e,
+                                          stdout=None if r == 0 else sys.stderr))
+        status = [None] * world
+        while any(s is None for s in status):
+            for r, p in enumerate(procs):
+                if status[r] is None:
+                    status[r] = p.poll()
+            if any(s not in (None, 0) for s in status):
+                break
+            time.sleep(poll_s)
+    finally:
+        for p in procs:                       # a failed rank (or an interrupt here) ends the job
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    codes = [p.returncode for p in procs]
+    bad = [c for c in codes if c != 0]
+    if not bad:
+        return 0
+    pos = [c for c in bad if c > 0]
+    return max(pos) if pos else 128 + max(-c for c in bad)      # a rank killed by signal s reads as 128 + s
+
+
 # ---- placement of a rank on the host ---------------------------------------------------------------------------------
 # Every exported frame crosses the GPU's PCIe link into a pinned host ring (24.9 MB per 4K frame, 57 GB/s per GPU).  On a
 # two-socket node the ring and the threads that drain it belong on the socket the GPU hangs off: a ring on the other

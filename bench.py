@@ -142,6 +142,11 @@ def main():
     args = parse_args()
     # multi-process GPU work on this pool needs dmabuf IPC (already exported there; kept if the launcher dropped it)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process has imported nothing that touches a GPU, so it
+        # starts N fresh ranks of itself (one per GPU), forwards rank 0's JSON line and exits with the worst status
+        from aurora_amd.sharding import launch_ranks
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], os.path.abspath(__file__)))
     import torch
     import torch.distributed as dist
 
@@ -149,8 +154,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
     # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share a card for rehearsals on a 1-GPU box
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")

@@ -391,6 +391,10 @@ class HipExportEngine:
         self.fill_events = None           # benchmarks set a list: (start, end, n_frames) HIP events around every plane fill
         import os
         self.direct_stroke = os.environ.get("AUR_DIRECT_STROKE", "1") != "0"   # A/B knob: 0 = always through the stroke plane
+        try:                                         # what aur_create read into ctx->fill_mode (csrc/abi.hip)
+            self.fill_mode = int(os.environ.get("AUR_FILL_MODE", "0") or 0)
+        except ValueError:
+            self.fill_mode = 0
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):
@@ -1004,10 +1008,14 @@ class HipExportEngine:
             ev.append((e0, e1, count))
         return out
 
-    def _direct_stroke_ok(self, W: int, out, decorated: bool):
-        """No translucent layer needs the stroke plane as an exclusion mask, and the frame shape is the linear fill's."""
+    def _direct_stroke_ok(self, W: int, H: int, count: int, out, decorated: bool):
+        """No translucent layer needs the stroke plane as an exclusion mask, and frame shape and batch are ones
+        aur_raster_closed_path takes (its own preconditions, csrc/radial.hip: the linear fill's shapes, the row-tile
+        A/B knob AUR_FILL_MODE=1 off, 32-bit piece indices); everything else goes through the stroke plane."""
+        upf = (W * 3 // 16) * H                      # 16-byte pieces per frame
         return (self.direct_stroke and not decorated and W % 32 == 0 and out is not None and out.is_contiguous()
-                and out.data_ptr() % 16 == 0)
+                and out.data_ptr() % 16 == 0 and self.fill_mode != 1
+                and 256 <= upf < (1 << 26) and count * upf + 256 < (1 << 31))
 
     def render_radial(self, prep: RadialPrep, an: Analysis, sc: Scan, W: int, H: int, first: int = 0,
                       count: int | None = None, out=None, planes_out=None, fill: FillConfig | None = None,
@@ -1022,7 +1030,7 @@ class HipExportEngine:
         want_glow = glow is not None and glow.active
         if out is None:
             out = self.empty((count, H, W, 3), self.torch.uint8)
-        if self._direct_stroke_ok(W, out, want_fill or want_shadow or want_glow):
+        if self._direct_stroke_ok(W, H, count, out, want_fill or want_shadow or want_glow):
             if prep.cfg.disc_static and prep.image is None:
                 sd = self._static_disc(prep, an, sc, W, H, first)
                 disc, rows = sd["full"], sd["rows"]          # the disc does not change: its row table is built once
@@ -1121,7 +1129,7 @@ class HipExportEngine:
         want_glow = glow is not None and glow.active
         if out is None:
             out = self.empty((count, H, W, 3), self.torch.uint8)
-        if self._direct_stroke_ok(W, out, want_fill or want_shadow or want_glow):
+        if self._direct_stroke_ok(W, H, count, out, want_fill or want_shadow or want_glow):
             self.raster_closed_path(self.wave_circular_vertices(an, sc, W, H, first, count, rotation_deg),
                                     self._no_disc_plane(W, H), True, sc.pen_rgb[first:first + count], W, H, out,
                                     rows=self._no_disc_rows(W, H))

@@ -68,6 +68,9 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=240, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-cores CPU figure (0 = box share)")
     ap.add_argument("--yuv-leg", type=int, default=1, help="also time one export step in the opt-in yuv420p wire format")
+    ap.add_argument("--pipe-frames", type=int, default=960,
+                    help="frames of the pipe leg: the same export through the product's pipe sink into a child process "
+                         "that reads stdin as FFmpeg does (0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),
                     help="per-launch HBM bytes from separate rocprofv3 --pmc passes (see profiles/README.md)")
     ap.add_argument("--isa-json", default=os.path.join(ROOT, "profiles", "stft_isa.json"),
@@ -83,10 +86,15 @@ def _cpu_export(job):
     from aurora_amd import synth
     from oracle import analysis_ref as A      # checker / baseline only
     from oracle import raster_ref as R
-    mode, sr, fps, W, H, frames, seed, signal = job
+    mode, sr, fps, W, H, frames, seed, signal = job[:8]
+    piped = len(job) > 8 and job[8]
     n = int(frames * sr / fps)
     audio = synth.sweep(n, sr, 2) if signal == "sweep" else synth.pink(n, 2, seed=seed)
     sunk = 0
+    child = None
+    if piped:                                          # exporter.py:532-535: the reference's Popen, pipe left at 64 KiB
+        import subprocess
+        child = subprocess.Popen(_drain_cmd(), stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=10 ** 7)
     t0 = time.perf_counter()
     ref = A.analyze_track(audio, sr, fps)
     pen, _ = A.amp_to_color_track(ref["energy"])
@@ -94,8 +102,20 @@ def _cpu_export(job):
     for f in range(F):
         frame = R.render_frame(mode, ref["samples"][f], ref["logspec"][f], float(ref["energy"][f]), pen[f], W, H)
         frame = np.ascontiguousarray(frame)            # exporter.py:540
-        sunk += len(frame.tobytes())                   # exporter.py:542 -> null sink
+        if child is not None:
+            child.stdin.write(frame.tobytes())         # exporter.py:542
+        else:
+            sunk += len(frame.tobytes())               # exporter.py:542 -> null sink
+    if child is not None:
+        child.stdin.close()
+        rep = json.loads(child.stdout.read())
+        child.wait()
+        assert rep["bytes"] == F * W * H * 3
     return F, time.perf_counter() - t0
+
+
+def _drain_cmd():
+    return [sys.executable, os.path.join(ROOT, "tools", "pipe_drain.py")]
 
 
 def cpu_baseline(args):
@@ -106,6 +126,12 @@ def cpu_baseline(args):
            "sample": f"first {F} frames ({F / fps:.1f} s of audio) of the same workload: numpy oracle analysis + software "
                      f"rasteriser + ascontiguousarray/tobytes into a null sink, {dt:.1f} s on 1 core (the reference "
                      f"exports in one process, export/worker.py)"}
+    if args.pipe_frames > 0:                         # the boundary the reference ends at: proc.stdin.write into a reading child
+        per = max(30, args.cpu_frames // 2)
+        Fp, dtp = _cpu_export((args.mode, sr, fps, W, H, per, 1234, args.signal, True))
+        out["piped"] = {"value": round(Fp / dtp, 2), "unit": "frames/s", "cores": 1,
+                        "sample": f"first {Fp} frames, frame.tobytes() written to the stdin of a child that reads and "
+                                  f"discards (the reference's Popen: bufsize 10**7, 64 KiB pipe), {dtp:.1f} s"}
     # courtesy whole-host figure: independent processes over disjoint time ranges of the track
     procs = args.cpu_procs or min(16, os.cpu_count() or 1)      # a 1-GPU box's CPU share is 16 (nproc shows the machine)
     if procs > 1:
@@ -255,6 +281,37 @@ def main():
         yuv_bytes = p2.frame_bytes
         p2.close()
         del p2
+    # ------------------------------------------------------------------ pipe leg: the boundary the reference ends at
+    # export/exporter.py:532-542 ends at proc.stdin.write: the same export through the product's own pipe sink
+    # (aurora_amd.export.exporter._PipeSink behind _grow_pipe) into a fresh child that reads stdin and discards
+    pipe_leg = None
+    if args.pipe_frames > 0 and rank == 0 and args.steps > 0:
+        import subprocess
+        from aurora_amd.export.exporter import _PipeSink, _grow_pipe
+        PF = min(F, args.pipe_frames)
+
+        def piped(wire, splice):
+            p = FramePipeline(eng, track, export_mode, W, H, frame_end=PF, batch_frames=min(B, PF), slots=args.slots,
+                              wire_format=wire, glow=GlowConfig(enabled=True) if args.glow else None).prepare()
+            child = subprocess.Popen(_drain_cmd(), stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=10 ** 7)
+            cap = _grow_pipe(child.stdin)
+            sink = _PipeSink(child.stdin, splice=splice)
+            torch.cuda.synchronize(device)
+            t = time.perf_counter()
+            n = p.run(sink)
+            child.stdin.close()
+            rep = json.loads(child.stdout.read())
+            child.wait()
+            t = time.perf_counter() - t
+            p.close()
+            assert n == PF and rep["bytes"] == PF * p.frame_bytes
+            return {"fps": round(PF / t, 1), "gbs": round(PF * p.frame_bytes / t / 1e9, 2), "bytes_per_frame": p.frame_bytes,
+                    "pipe_bytes": cap, "spliced_frac": round(sink.spliced_bytes / max(1, rep["bytes"]), 4)}
+
+        pipe_leg = {"frames": PF, "reader": "tools/pipe_drain.py: read() of 4 MiB into its own buffer, discards",
+                    "rgb24": piped("rgb24", None), "rgb24_plain_write": piped("rgb24", False)}
+        if W % 4 == 0 and H % 2 == 0:
+            pipe_leg["yuv420p"] = piped("yuv420p", None)
     del track, audio
     torch.cuda.empty_cache()
 
@@ -412,6 +469,7 @@ def main():
             "device_leg": device_leg,
             "yuv420p_leg": ({"fps": round(yuv_fps, 1), "link_gbs": round(yuv_fps * yuv_bytes / 1e9, 2),
                              "bytes_per_frame": yuv_bytes} if yuv_fps else None),
+            "pipe_leg": pipe_leg,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

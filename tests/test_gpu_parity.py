@@ -8,10 +8,13 @@ Bars:
  * raster: BIT-EXACT against the oracle rasteriser when both are fed the same analysis values; end to end
    (GPU spectrum vs oracle spectrum) PSNR >= 50 dB and only bar-height flips of one row allowed.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
-from conftest import golden_analysis_names, load_golden
+from conftest import REPO, golden_analysis_names, load_golden
 from oracle import analysis_ref as A
 from oracle import raster_ref as R
 
@@ -1522,3 +1525,47 @@ def test_closed_path_entry_with_irregular_discs(eng, disc_kind):
     got2 = torch.full((F, H, W, 3), 0xA5, dtype=torch.uint8, device=eng.device)
     eng.raster_closed_path(verts, d_disc, nd == 1, pen, W, H, got2, rows=rows)
     assert np.array_equal(_np(got2), want)
+
+
+def test_closed_path_modes_outside_the_direct_entry_points_shapes(eng, tmp_path):
+    """aur_raster_closed_path refuses the row-tile A/B knob (AUR_FILL_MODE=1), frames under 256 16-byte pieces and batches
+    past 2^31 pieces; the engine then goes through the stroke plane instead of raising.  A child with
+    AUR_FILL_MODE=1 and a 64x16 frame in this process render the frames the default path renders."""
+    import hashlib
+    import subprocess
+    import sys
+    from aurora_amd import synth
+    from aurora_amd.pipeline import FramePipeline
+    audio = synth.pink(9000, 2, seed=12)
+    track = eng.upload_track(audio, 48000, 60)
+    want = {}
+    for mode in ("Spectrum - Radial", "Waveform - Circular"):
+        for W, H in ((640, 360), (64, 16)):
+            assert eng._direct_stroke_ok(W, H, 4, eng.empty((4, H, W, 3), eng.torch.uint8), False) == (H == 360)
+            frames = _np(FramePipeline(eng, track, mode, W, H).render_device())
+            want[f"{mode}|{W}x{H}"] = hashlib.sha256(frames.tobytes()).hexdigest()
+            if H == 16:                       # the small frame took the plane path: same pixels as the per-pixel rule
+                eng.direct_stroke = False
+                try:
+                    again = _np(FramePipeline(eng, track, mode, W, H).render_device())
+                finally:
+                    eng.direct_stroke = True
+                assert np.array_equal(frames, again)
+    # far past the 32-bit piece index of one call: refused by the predicate, not by the C entry point
+    assert not eng._direct_stroke_ok(3840, 2160, 1400, eng.empty((1, 16, 64, 3), eng.torch.uint8), False)
+    code = ("import sys, json, hashlib; sys.path.insert(0, %r)\n"
+            "from aurora_amd import synth\n"
+            "from aurora_amd.engine import get_engine\n"
+            "from aurora_amd.pipeline import FramePipeline\n"
+            "eng = get_engine(0); assert eng.fill_mode == 1\n"
+            "track = eng.upload_track(synth.pink(9000, 2, seed=12), 48000, 60)\n"
+            "out = {}\n"
+            "for mode in ('Spectrum - Radial', 'Waveform - Circular'):\n"
+            "    for W, H in ((640, 360), (64, 16)):\n"
+            "        fr = FramePipeline(eng, track, mode, W, H).render_device().cpu().numpy()\n"
+            "        out[f'{mode}|{W}x{H}'] = hashlib.sha256(fr.tobytes()).hexdigest()\n"
+            "print(json.dumps(out))\n" % REPO)
+    env = dict(os.environ, AUR_FILL_MODE="1")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=200)
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert json.loads(res.stdout.strip().splitlines()[-1]) == want

@@ -360,24 +360,37 @@ def build_ffmpeg_segment_cmd(width: int, height: int, fps: int, out_path: str, p
 class _PipeSink:
     """The write end of the pipe into FFmpeg (``proc.stdin.write(frame.tobytes())``, exporter.py:542).
 
-    The pipeline hands over whole ring slots (about 1 GiB of frames that already sit in page-locked memory).  A plain
-    ``write`` makes the kernel copy every byte into pipe pages before the reader copies it out again; ``vmsplice`` puts
-    the slot's own pages into the pipe instead, which leaves the reader's copy as the only one (measured 2.1 -> 5.8 GB/s
-    against a reading child, ``tools/pipe_lab.py``).  Spliced pages stay referenced by the pipe until the reader has
-    taken them, and the caller reuses its buffer as soon as ``write`` returns, so the last ``capacity`` bytes of every
-    buffer go through an ordinary ``write``: a pipe is first-in first-out and holds at most ``capacity`` bytes in pages
-    of 4 KiB, so by the time that copy has fitted, every spliced page before it has left the pipe.  ``write`` therefore
-    means what it always meant: on return the pipe refers to nothing of the caller's memory.
+    The pipeline hands over whole ring slots (about 1 GiB of frames in page-locked memory).  A plain ``write`` makes the
+    kernel allocate a pipe page and copy into it for every 4 KiB, one thread, before the reader copies it out again
+    (3.6 GB/s = 145 4K frames/s measured on the MI355X box, ``profiles/r03_pipe_*``).  ``vmsplice`` puts user pages into the
+    pipe instead, which leaves the reader's copy as the only single-threaded one (26 GB/s against the same reader).
 
-    Buffers under ``4 * capacity``, hosts without ``vmsplice`` and memory the kernel refuses to splice (EFAULT / EINVAL on
-    the first try) take the plain path.  ``AUR_PIPE_SPLICE=0`` turns splicing off."""
+    * **direct**: ordinary (pageable) caller memory is spliced as it is.  Spliced pages stay referenced by the pipe until
+      the reader has taken them, and the caller reuses its buffer as soon as ``write`` returns, so the last ``capacity``
+      bytes of every buffer go through an ordinary ``write``: a pipe is first-in first-out and holds at most ``capacity``
+      bytes in pages of 4 KiB, so by the time that copy has fitted, every spliced page before it has left the pipe.
+    * **staged**: the ring itself cannot be spliced -- ``hipHostMalloc`` memory is a device-file mapping (``vmsplice``
+      answers EFAULT) and this pool refuses ``hipHostRegister`` of anonymous memory (``profiles/r03_hostreg_probe.txt``) --
+      so chunks of it are copied by a few threads into three page-aligned staging buffers of the sink's own and spliced
+      from there; a staging buffer is overwritten only after a whole later chunk (at least ``capacity`` bytes) has been
+      spliced behind it, which by the same first-in first-out argument means its pages have left the pipe.
 
-    def __init__(self, stdin, splice=None):
+    Either way ``write`` means what it always meant: on return the pipe refers to nothing of the caller's memory.
+    Buffers under ``4 * capacity`` and hosts without ``vmsplice`` take the plain path.  ``AUR_PIPE_SPLICE=0`` turns
+    splicing off, ``AUR_PIPE_COPY_THREADS`` sets the staging copy threads (default 4)."""
+
+    CHUNK = 16 << 20
+
+    def __init__(self, stdin, splice=None, staged=None):
         self._stdin = stdin
         self.spliced_bytes = 0
         self.copied_bytes = 0
+        self.refused_errno = None         # errno of the vmsplice call that sent this sink to the staged path
         self._fd = None
         self._cap = 0
+        self._staged = bool(staged)       # None / False: found out from the first refusal
+        self._stage = None                # (buffers, thread pool), made on first use
+        self._turn = 0
         if splice is None:
             splice = os.environ.get("AUR_PIPE_SPLICE", "1") != "0"
         if splice:
@@ -388,7 +401,7 @@ class _PipeSink:
                 self._vmsplice = _libc_vmsplice()
             except Exception:
                 self._fd = None
-            if self._fd is not None and (self._vmsplice is None or self._cap <= 0):
+            if self._fd is not None and (self._vmsplice is None or self._cap <= 0 or 4 * self._cap > self.CHUNK):
                 self._fd = None
 
     def write(self, buf):
@@ -400,15 +413,77 @@ class _PipeSink:
             return
         self._stdin.flush()                                  # nothing of an earlier write may overtake these bytes
         flat = np.frombuffer(view, dtype=np.uint8)
-        head = n - self._cap
-        off = self._splice(flat.ctypes.data, head)
-        if off < head:                                       # refused: this memory cannot be spliced, stay with write
-            self._fd = None
+        off = 0
+        if not self._staged:
+            head = n - self._cap
+            off = self._splice(flat.ctypes.data, head)
+            if off < head:                                   # refused before a byte went in: not spliceable memory
+                self._staged = True
+        if self._staged and off == 0:
+            self._write_staged(flat)
+            return
         self.spliced_bytes += off
         self.copied_bytes += n - off
         rest = view.cast("B")[off:]
         while len(rest):
-            rest = rest[os.write(self._stdin.fileno(), rest):]
+            rest = rest[os.write(self._fd, rest):]
+
+    # ---- staged path -------------------------------------------------------------------------------------------------
+    def _staging(self):
+        if self._stage is None:
+            import mmap
+            from concurrent.futures import ThreadPoolExecutor
+            size = self.CHUNK + self._cap
+            maps = [mmap.mmap(-1, size) for _ in range(3)]                       # page-aligned, the sink's own
+            bufs = [np.frombuffer(m, dtype=np.uint8) for m in maps]
+            threads = max(1, int(os.environ.get("AUR_PIPE_COPY_THREADS", "4") or 4))
+            self._stage = (bufs, ThreadPoolExecutor(threads, thread_name_prefix="aurora-pipe-stage"), threads, maps)
+        return self._stage
+
+    def _copy_into(self, slot, src):
+        """Starts the copy of ``src`` into staging buffer ``slot`` on the pool; returns the futures."""
+        bufs, pool, threads, _ = self._staging()
+        n = src.size
+        step = ((n + threads - 1) // threads + 4095) // 4096 * 4096          # whole pages per thread
+        return [pool.submit(np.copyto, bufs[slot][o:min(n, o + step)], src[o:min(n, o + step)])
+                for o in range(0, n, step)]
+
+    def _write_staged(self, flat):
+        n, chunk = flat.size, self.CHUNK
+        cuts = list(range(0, n, chunk))
+        if len(cuts) > 1 and n - cuts[-1] < self._cap:       # every chunk holds at least `capacity` bytes
+            cuts.pop()
+        cuts.append(n)
+        bufs = self._staging()[0]
+        pending = self._copy_into(self._turn % 3, flat[cuts[0]:cuts[1]])
+        try:
+            for k in range(len(cuts) - 1):
+                for f in pending:
+                    f.result()
+                slot = self._turn % 3
+                self._turn += 1
+                pending = []
+                if k + 2 < len(cuts):
+                    # buffer (turn % 3) was last spliced two chunks ago; the chunk spliced after it has gone in whole
+                    pending = self._copy_into(self._turn % 3, flat[cuts[k + 1]:cuts[k + 2]])
+                size = cuts[k + 1] - cuts[k]
+                if self._splice(bufs[slot].ctypes.data, size) != size:
+                    raise OSError(self.refused_errno or errno.EIO, "vmsplice refused the sink's own staging buffer")
+                self.spliced_bytes += size
+        finally:
+            for f in pending:                                # never leave a copy running into the caller's buffer
+                f.cancel()
+            for f in pending:
+                if not f.cancelled():
+                    try:
+                        f.result()
+                    except Exception:
+                        pass
+
+    def close(self):
+        if self._stage is not None:
+            self._stage[1].shutdown(wait=True)
+            self._stage = None
 
     def _splice(self, addr, nbytes):
         """vmsplice ``nbytes`` at ``addr``; returns how many went in (less than asked only if the kernel refused the
@@ -424,7 +499,8 @@ class _PipeSink:
                     continue
                 if e == errno.EPIPE:
                     raise BrokenPipeError(e, os.strerror(e))
-                if off == 0 and e in (errno.EFAULT, errno.EINVAL, errno.ENOSYS, errno.EBADF):
+                if off == 0 and e in (errno.EFAULT, errno.EINVAL, errno.ENOSYS, errno.EBADF, errno.ENOMEM):
+                    self.refused_errno = e
                     return 0
                 raise OSError(e, os.strerror(e))
             off += k
@@ -575,9 +651,11 @@ class Exporter:
         _grow_pipe(proc.stdin)
         tail = _TailReader(proc.stderr, keep=1 << 16)
         sinkhole = _TailReader(proc.stdout, keep=0)
+        sink = _PipeSink(proc.stdin)
         try:
-            self._pump(renderer, _PipeSink(proc.stdin), progress_cb)
+            self._pump(renderer, sink, progress_cb)
         finally:
+            sink.close()
             try:
                 if proc.stdin:
                     proc.stdin.close()

@@ -304,9 +304,12 @@ def main():
             child.wait()
             t = time.perf_counter() - t
             p.close()
+            sink.close()
             assert n == PF and rep["bytes"] == PF * p.frame_bytes
+            how = ("write" if sink.spliced_bytes == 0 else
+                   "staged vmsplice (ring memory refused: errno %s)" % sink.refused_errno if sink._staged else "vmsplice")
             return {"fps": round(PF / t, 1), "gbs": round(PF * p.frame_bytes / t / 1e9, 2), "bytes_per_frame": p.frame_bytes,
-                    "pipe_bytes": cap, "spliced_frac": round(sink.spliced_bytes / max(1, rep["bytes"]), 4)}
+                    "pipe_bytes": cap, "path": how, "spliced_frac": round(sink.spliced_bytes / max(1, rep["bytes"]), 4)}
 
         pipe_leg = {"frames": PF, "reader": "tools/pipe_drain.py: read() of 4 MiB into its own buffer, discards",
                     "rgb24": piped("rgb24", None), "rgb24_plain_write": piped("rgb24", False)}

@@ -217,9 +217,72 @@ def test_closed_path_frames_vs_oracle_own_chain(eng, track4min, pool, mode, size
           f"(rate {rate:.5f}); worst frame: {int(ndiff.max())} pixels differ, {int(nbad.max())} by more than 1 LSB, "
           f"min PSNR {ps.min():.1f} dB")
     if radial:
-        assert ps.min() >= 50.0 and ndiff.max() <= 16 and rate <= 0.05, (rate, int(ndiff.max()))
+        # measured on MI355X: 1 of 480 frames at 1080p, 3 of 240 at 4K, one pixel each
+        assert ps.min() >= 50.0 and ndiff.max() <= 2 and flipped <= (3 if H == 1080 else 6), (flipped, int(ndiff.max()))
     else:
         assert flipped == 0
+
+
+def test_config3_union_composite_at_its_own_size(eng, track4min, pool):
+    """BASELINE configs[3] ("particle mode + audio-reactive image feather", 1920x1080@60) at ITS size with the settings
+    `bench.py --mode "Particles + Feather"` times: particle frames with the audio-reactive disc envelope and the six
+    feather rings composited from planes of the feather box (`feather_blend(..., with_disc=True)`; the box depends on
+    min(W, H), so 1080p is its own geometry).  48 frames sampled from the 4-minute track, two bars:
+    (a) against the oracle composite of the GPU's own envelope / ring vertices and spectrum: bit-exact;
+    (b) against the oracle's own chain (its spectrum, `envelope_path`, `feather_ring_paths`, rt_widget.py:1007-1051,
+        :1098-1117): a vertex that differs in the last place (device sin / the spectrum's last ulp) may flip an edge pixel;
+        the count is printed and bounded."""
+    import torch
+    from _frame_compare_worker import compare_union_frame
+    from aurora_amd.engine import RadialConfig
+    from oracle import radial_ref as RR
+    track, an, sc, ref, pen = track4min
+    W, H = 1920, 1080
+    F = track.total_frames
+    picks = [int(f) for f in np.unique(np.linspace(0, F - 1, 48).astype(np.int64))]
+    cfg = RadialConfig(feather_enabled=True, feather_audio_enabled=True, feather_audio_amount=60, edge_waviness=40)
+    params = RR.RadialParams(feather_enabled=True, feather_audio_enabled=True, feather_audio_amount=60, edge_waviness=40)
+    prep = eng.radial_prepare(an, cfg)
+    phase = A.phase_track(ref["energy"])
+    alphas = [max(10, 70 - 10 * k) for k in range(1, 7)]
+    fb = W * H * 3
+    shm = shared_memory.SharedMemory(create=True, size=len(picks) * fb)
+    try:
+        view = np.ndarray((len(picks), H, W, 3), dtype=np.uint8, buffer=shm.buf)
+        own, chain = [], []
+        ls_gpu, en_gpu, pen_gpu = an.logspec, sc.energy, sc.pen_rgb
+        for j, f in enumerate(picks):
+            frame = eng.render("Particles", an, sc, W, H, f, 1)
+            eng.feather_blend(prep, an, sc, W, H, f, 1, frame, with_disc=True)
+            view[j] = frame[0].cpu().numpy()
+            env = eng._envelope(prep, an, sc, W, H, f, 1)[0].cpu().numpy()
+            rings = eng.feather_ring_vertices(prep, an, sc, W, H, f, 1)[0].cpu().numpy()
+            own.append((shm.name, j * fb, ls_gpu[f].cpu().numpy(), float(en_gpu[f].item()),
+                        pen_gpu[f].cpu().numpy()[:3], env, list(rings), alphas, W, H))
+            e = float(ref["energy"][f])
+            want_env = RR.envelope_path(ref["logspec"][f], e, float(phase[f]), W, H, params)
+            want_rings = RR.feather_ring_paths(ref["logspec"][f], e, float(phase[f]), W, H, params)
+            assert [a for _, a in want_rings] == alphas
+            assert np.max(np.abs(env - want_env)) <= 2e-3 and max(np.max(np.abs(r - w[0])) for r, w in zip(rings, want_rings)) <= 2e-3
+            chain.append((shm.name, j * fb, ref["logspec"][f], e, pen[f], want_env, [v for v, _ in want_rings], alphas, W, H))
+        bx, by, bw, bh = eng.feather_box(cfg, W, H)
+        assert (bw, bh) != (W, H) and bx % 32 == 0          # planes of the box, not of the frame
+        res_own = pool.map(compare_union_frame, own)
+        res_chain = pool.map(compare_union_frame, chain)
+        changed = int(np.sum(np.any(view[0] != eng.render("Particles", an, sc, W, H, picks[0], 1)[0].cpu().numpy(), axis=2)))
+        del view
+    finally:
+        shm.close()
+        shm.unlink()
+    assert changed > 50_000                                 # the disc and its rings are in the frame
+    bad_own = [(f, r[0]) for f, r in zip(picks, res_own) if r[0]]
+    assert not bad_own, bad_own
+    ndiff = np.array([r[0] for r in res_chain])
+    ps = np.array([r[2] for r in res_chain])
+    print(f"\nconfigs[3] union composite 1920x1080: GPU == oracle on its own vertices for all {len(picks)} frames; against "
+          f"the oracle's own chain {int(np.count_nonzero(ndiff))} frames differ, worst {int(ndiff.max())} pixels, "
+          f"min PSNR {ps.min():.1f} dB")
+    assert ps.min() >= 50.0 and ndiff.max() <= 24
 
 
 def _ulps(a, b):

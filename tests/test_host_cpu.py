@@ -741,7 +741,7 @@ def test_every_entry_point_rejects_a_null_context():
     assert lib.aur_host_alloc(None, 16) != 0 and lib.aur_host_free(None) == 0
 
 
-# ---- the pipe into FFmpeg: vmsplice of whole ring slots, last `capacity` bytes copied (exporter._PipeSink) --------------
+# ---- the pipe into FFmpeg: vmsplice of whole ring slots (exporter._PipeSink) -----------------------------------------------
 
 def _drain_child(extra=()):
     import subprocess
@@ -749,20 +749,25 @@ def _drain_child(extra=()):
                             stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=10 ** 7)
 
 
-@pytest.mark.parametrize("splice", [False, True])
-def test_pipe_sink_stream_is_the_written_bytes_even_when_buffers_are_reused(splice):
+_PIPE_SIZES = (24_000_011, 5, 4 * (1 << 20), 4 * (1 << 20) - 1, 1_000_003, 0, 16 << 20, (16 << 20) + 1, (17 << 20) - 1,
+               17 << 20, (32 << 20) + 100, 17_123_457, 40_000_001)
+
+
+@pytest.mark.parametrize("path", ["plain", "direct", "staged"])
+def test_pipe_sink_stream_is_the_written_bytes_even_when_buffers_are_reused(path):
     """A slow reader (4 KiB reads + sha256) keeps the pipe full; the writer overwrites its buffer the moment `write`
-    returns, as the pinned ring does.  The child must still see exactly the bytes that were handed over: spliced pages
-    have left the pipe by the time `write` returns (the tail rule of _PipeSink)."""
+    returns, as the pinned ring does.  The child must still see exactly the bytes that were handed over: on the direct
+    path spliced pages have left the pipe by the time `write` returns (the tail rule), on the staged path the caller's
+    memory is never in the pipe and a staging buffer is reused only after a whole later chunk went in behind it."""
     import hashlib
     from aurora_amd.export.exporter import _PipeSink, _grow_pipe
     child = _drain_child(("--chunk", "4096"))
     cap = _grow_pipe(child.stdin)
-    sink = _PipeSink(child.stdin, splice=splice)
+    sink = _PipeSink(child.stdin, splice=path != "plain", staged=path == "staged")
     rng = np.random.default_rng(5)
-    buf = np.empty(24_000_011, np.uint8)
+    buf = np.empty(max(_PIPE_SIZES), np.uint8)
     want, total = hashlib.sha256(), 0
-    for n in (24_000_011, 5, 4 * (1 << 20), 4 * (1 << 20) - 1, 1_000_003, 0, 17_123_457, 24_000_011):
+    for n in _PIPE_SIZES:
         part = buf[:n]
         part[:] = rng.integers(0, 256, size=n, dtype=np.uint8)
         want.update(part.tobytes())
@@ -771,47 +776,59 @@ def test_pipe_sink_stream_is_the_written_bytes_even_when_buffers_are_reused(spli
         buf[:] = 0xEE                                   # the slot is reused at once
     child.stdin.close()
     rep = json.loads(child.stdout.read())
+    sink.close()
     assert child.wait() == 0
     assert rep["bytes"] == total and rep["sha256"] == want.hexdigest()
-    assert sink.spliced_bytes + sink.copied_bytes == total
-    if splice and cap and sink._vmsplice is not None:
-        # every buffer of at least 4 pipe capacities went through vmsplice except its last `capacity` bytes
-        big = [n for n in (24_000_011, 4 * (1 << 20), 17_123_457, 24_000_011) if n >= 4 * cap]
-        assert sink.spliced_bytes == sum(n - cap for n in big)
+    big = [n for n in _PIPE_SIZES if cap and n >= 4 * cap]
+    if path == "plain" or sink._vmsplice is None or not cap:
+        assert sink.spliced_bytes == 0 and sink.copied_bytes == total
+    elif path == "direct":
+        assert sink.spliced_bytes == sum(n - cap for n in big)      # all but the last `capacity` bytes of a big buffer
+        assert sink.spliced_bytes + sink.copied_bytes == total
     else:
-        assert sink.spliced_bytes == 0
+        assert sink.spliced_bytes == sum(big) and sink.copied_bytes == total - sum(big)
 
 
 def test_pipe_sink_broken_pipe_and_refused_memory(monkeypatch):
     import subprocess
     from aurora_amd.export import exporter as E
     # the reader goes away: BrokenPipeError, which the pipeline treats as "stop writing" (exporter.py:543-544)
-    child = subprocess.Popen([sys.executable, "-c", "import sys; sys.stdin.buffer.read(1 << 16)"], stdin=subprocess.PIPE)
+    for staged in (False, True):
+        child = subprocess.Popen([sys.executable, "-c", "import sys; sys.stdin.buffer.read(1 << 16)"], stdin=subprocess.PIPE)
+        E._grow_pipe(child.stdin)
+        sink = E._PipeSink(child.stdin, splice=True, staged=staged)
+        big = np.zeros(64 << 20, np.uint8)
+        with pytest.raises(BrokenPipeError):
+            for _ in range(8):
+                sink.write(memoryview(big))
+        sink.close()
+        child.wait()
+    # memory the kernel will not splice (EFAULT, as for hipHostMalloc memory): the sink stages it from then on
+    child = _drain_child()
     E._grow_pipe(child.stdin)
     sink = E._PipeSink(child.stdin, splice=True)
-    big = np.zeros(64 << 20, np.uint8)
-    with pytest.raises(BrokenPipeError):
-        for _ in range(8):
-            sink.write(memoryview(big))
-    child.wait()
-    # memory the kernel will not splice (EFAULT on the first call): the sink falls back to write for good
-    child = _drain_child()
-    sink = E._PipeSink(child.stdin, splice=True)
-    calls = []
+    data = np.arange(40 << 20, dtype=np.uint8)
+    lo, hi = data.ctypes.data, data.ctypes.data + data.nbytes
+    real, refused = sink._vmsplice, []
 
-    def refuse(fd, iov, n, flags):
-        calls.append(1)
-        ctypes.set_errno(14)                                  # EFAULT
-        return -1
+    def picky(fd, iov, n, flags):
+        base = ctypes.cast(iov, ctypes.POINTER(E._IoVec)).contents.iov_base
+        if lo <= base < hi:
+            refused.append(base)
+            ctypes.set_errno(14)                              # EFAULT
+            return -1
+        return real(fd, iov, n, flags)
 
-    monkeypatch.setattr(sink, "_vmsplice", refuse)
-    data = np.arange(9 << 20, dtype=np.uint8)
+    monkeypatch.setattr(sink, "_vmsplice", picky)
+    import hashlib
     sink.write(memoryview(data))
     sink.write(memoryview(data))
     child.stdin.close()
     rep = json.loads(child.stdout.read())
+    sink.close()
     child.wait()
-    assert rep["bytes"] == 2 * data.nbytes and len(calls) == 1 and sink.spliced_bytes == 0
+    assert rep["bytes"] == 2 * data.nbytes and rep["sha256"] == hashlib.sha256(data.tobytes() * 2).hexdigest()
+    assert len(refused) == 1 and sink.refused_errno == 14 and sink.spliced_bytes == 2 * data.nbytes
     # AUR_PIPE_SPLICE=0 turns it off
     monkeypatch.setenv("AUR_PIPE_SPLICE", "0")
     child = _drain_child()

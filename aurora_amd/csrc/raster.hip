@@ -15,6 +15,8 @@
 // the rows of its tile with its columns' spans held in registers.
 #include "common.h"
 
+#include <mutex>
+
 namespace {
 
 constexpr double kBig = 1.0e6;
@@ -713,11 +715,31 @@ extern "C" int aur_raster_spans_ws(aur_ctx* ctx, const uint32_t* d_spans, int K,
 // anything but that look-up.
 static __device__ __align__(256) unsigned char scratch[AUR_STATIC_WORK_BYTES];
 
+// Every call on a GPU shares that GPU's array.  Calls on one stream are ordered by the stream; a call on ANOTHER stream
+// while the previous call's kernels may still be running would rewrite summaries those kernels read.  The library keeps,
+// per device, the stream of the last call and an event recorded behind it (created in aur_create, never in the entry
+// point), and refuses such a call instead of racing: hipEventQuery, no allocation, no synchronisation.  Streams under
+// graph capture are exempt on both sides (an event recorded there is a graph node and cannot be queried): launches
+// inside one captured graph are ordered by the graph's own edges, which is the caller's business.
+constexpr int kMaxGuardDevices = 64;
+struct StaticGuard {
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+    bool pending = false;
+};
+static StaticGuard g_guard[kMaxGuardDevices];
+static std::mutex g_guard_mu;
+
 int aur_raster_static_init(aur_ctx* ctx) {
     void* p = nullptr;
     AUR_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));      // the context's device is current (aur_create)
     AUR_REQUIRE(p != nullptr && ((uintptr_t)p & 255u) == 0, "aur_create: static work area unresolved or misaligned");
     ctx->d_static_work = p;
+    if (ctx->device >= 0 && ctx->device < kMaxGuardDevices) {
+        std::lock_guard<std::mutex> lock(g_guard_mu);
+        if (g_guard[ctx->device].done == nullptr)
+            AUR_CHECK_HIP(hipEventCreateWithFlags(&g_guard[ctx->device].done, hipEventDisableTiming));
+    }
     return AUR_OK;
 }
 
@@ -735,10 +757,40 @@ extern "C" int aur_raster_spans_static(aur_ctx* ctx, const uint32_t* d_spans, in
                 "(split the batch: at most %d frames of this width per call)",
                 n_frames, W, need, AUR_STATIC_WORK_BYTES,
                 (int)((size_t)AUR_STATIC_WORK_BYTES / raster_work_bytes(1, W)));
+    hipStream_t st = (hipStream_t)stream;
+    StaticGuard* g = (ctx->device >= 0 && ctx->device < kMaxGuardDevices) ? &g_guard[ctx->device] : nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (g != nullptr && hipStreamIsCapturing(st, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
+    const bool guarded = g != nullptr && g->done != nullptr && cap == hipStreamCaptureStatusNone;
+    std::unique_lock<std::mutex> lock(g_guard_mu, std::defer_lock);
+    if (guarded) {
+        lock.lock();                            // held over the launch: two threads cannot both pass the check
+        if (g->pending && g->last != st) {
+            const hipError_t q = hipEventQuery(g->done);
+            if (q == hipErrorNotReady) {
+                aur_set_error("aur_raster_spans_static: the previous call on this GPU (stream %p) has not finished and this "
+                              "call is on another stream (%p): both would use the one static work area; order the streams "
+                              "(event / synchronise) or use aur_raster_spans_ws with a work area per stream",
+                              (void*)g->last, (void*)st);
+                return AUR_EINVAL;
+            }
+            if (q != hipSuccess) (void)hipGetLastError();
+            g->pending = false;
+        }
+    }
     // the summary kernel rewrites every element the fill reads for this shape (summaries of all n_frames * nu4 columns,
     // merged intervals of all n_frames * W pixel columns), so nothing of the previous call's contents is ever read
-    return aur_raster_spans_ws(ctx, d_spans, K, d_pen_rgb, n_frames, W, H, d_frames, ctx->d_static_work,
-                               (size_t)AUR_STATIC_WORK_BYTES, 0, stream);
+    rc = aur_raster_spans_ws(ctx, d_spans, K, d_pen_rgb, n_frames, W, H, d_frames, ctx->d_static_work,
+                             (size_t)AUR_STATIC_WORK_BYTES, 0, stream);
+    if (guarded && rc == AUR_OK && n_frames > 0) {
+        AUR_CHECK_HIP(hipEventRecord(g->done, st));
+        g->last = st;
+        g->pending = true;
+    }
+    return rc;
 }
 
 extern "C" int aur_raster_spans(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb, int n_frames,

@@ -162,6 +162,7 @@ class HipOffscreenRenderer:
                                    background=BackgroundConfig.from_view_state(view_state))
         self.wire_format = self._pipe.wire_format
         self._cache = None          # (first_frame, uint8 [n, H, W, 3] host array)
+        self._stepper = None        # state of the call-by-call path (render_time off the frame grid)
 
     # -- batched fast path used by Exporter._run_pipe ---------------------------------------------------
     def stream_to(self, sink, progress=None):
@@ -179,11 +180,49 @@ class HipOffscreenRenderer:
             c = self._cache = (i, frames.cpu().numpy())
         return c[1][i - c[0]]
 
-    def render_frame(self, t):
-        return self.render_frame_index(int(round(float(t) * self.fps)))
+    def render_frame(self, t, stepwise=None):
+        """Frame at time ``t`` (exporter.py:246-249).
 
-    def render_time(self, t):
-        return self.render_frame(t)
+        The reference's renderer is a state machine: every call reads ``hop`` samples at ``int(t * sr)`` (:227-237),
+        advances its analyser (previous block, previous magnitudes, flux EMA), its colour EMA and its phase by one step
+        and draws.  Its only caller asks for ``t = i / fps``, i = 0, 1, 2, ... (:539), and for those times this renderer
+        returns frame ``i`` of that sequence from the batched path without replaying the calls before it.  Any other
+        ``t`` (or ``stepwise=True``) is served literally: one step of a per-renderer state machine that starts from the
+        zero state at its first such call -- position ``int(t * sr)``, analysis through the same fused kernel over the
+        positions of the last three such calls, scan with the carried scalar state, ring EMA with the carried ring."""
+        x = float(t) * self.fps
+        i = int(round(x))
+        on_grid = abs(x - i) <= 1e-9 * max(1.0, abs(x))
+        if stepwise is None:
+            stepwise = not on_grid
+        if not stepwise:
+            return self.render_frame_index(i)
+        return self._step(float(t))
+
+    def render_time(self, t, stepwise=None):
+        return self.render_frame(t, stepwise)
+
+    def _step(self, t):
+        from ..engine import Track
+        eng, tr, torch = self._eng, self._track, self._eng.torch
+        st = self._stepper
+        if st is None:
+            st = self._stepper = {"pos": [], "state": None, "ring": None}
+        pos = int(max(0, min(tr.n_samples - 1, t * self.samplerate)))          # exporter.py:230
+        hist = (st["pos"] + [pos])[-3:]        # frame k needs block k, block k-1 and |X| of frame k-1 (blocks k-1, k-2)
+        st["pos"] = hist
+        table = np.asarray(hist, dtype=np.int64)
+        view = Track(tr.audio, torch.from_numpy(table).to(eng.device), table, tr.n_samples, tr.channels, tr.sample_rate,
+                     tr.fps, tr.hop, len(hist))
+        pipe = self._pipe
+        an = eng.analyze(view, len(hist) - 1, 1, want_samples=pipe.kind.startswith("waveform"))
+        sc = eng.scan(an, pipe.params, st["state"])
+        st["state"] = tuple(float(v) for v in sc.state.cpu().numpy())
+        prep = None
+        if pipe.radial is not None:
+            prep = eng.radial_prepare(an, pipe.radial, st["ring"])
+            st["ring"] = prep.state.clone() if pipe.radial.radial_temporal_alpha > 0.0 else None
+        return pipe.render_one(an, sc, prep)[0].cpu().numpy()
 
 
 # ----------------------------------------------------------------------------- ffmpeg utilities

@@ -153,6 +153,16 @@ class FramePipeline:
             if self._base is not None:
                 self.eng.set_background(None)
 
+    def render_one(self, an, sc, radial_prep=None):
+        """uint8 [1, H, W, 3] of ONE analysed frame whose analysis, scan and ring state the caller stepped itself
+        (`HipOffscreenRenderer.render_time` off the frame grid: the reference's call-by-call semantics)."""
+        saved = self._radial_prep
+        self._radial_prep = radial_prep
+        try:
+            return self._render(an, sc, 0, 1)
+        finally:
+            self._radial_prep = saved
+
     def _render_batch(self, an, sc, first, count, out=None, scratch=None):
         if self.radial is not None:
             return self.eng.render_radial(self._radial_prep, an, sc, self.W, self.H, first, count, out=out,

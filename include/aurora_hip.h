@@ -192,7 +192,11 @@ int aur_raster_spans_ws(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint
  * held until the process ends); a batch whose aur_raster_work_bytes(n_frames, W) exceeds it is rejected with AUR_EINVAL
  * (3840 wide: at most 148 frames per call; 1920: 297; 1280: 446).  Shapes the linear fill does not take (see
  * aur_raster_spans_ws) go to aur_raster_spans, which needs no work area.  All calls on one GPU share that GPU's array:
- * calls that overlap on one GPU (different streams, threads or contexts) race; calls on one stream are ordered and safe.
+ * calls on one stream are ordered by the stream and safe; a call that arrives on ANOTHER stream while the previous call on
+ * that GPU has not finished would race on the array and is refused with AUR_EINVAL (the library keeps, per GPU, the last
+ * call's stream and an event recorded behind it, created in aur_create and looked at with hipEventQuery: no allocation,
+ * no synchronisation).  Order the streams, or give each stream a work area of its own (aur_raster_spans_ws).  Streams
+ * under graph capture are not tracked: launches of one captured graph are ordered by the graph's own edges.
  * Results are byte-identical to aur_raster_spans_ws / aur_raster_spans. */
 #define AUR_STATIC_WORK_BYTES (3 * 1024 * 1024)
 int aur_raster_spans_static(aur_ctx* ctx, const uint32_t* d_spans, int K, const uint8_t* d_pen_rgb /*[F,4]*/,

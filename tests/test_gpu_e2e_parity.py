@@ -282,7 +282,7 @@ def test_config3_union_composite_at_its_own_size(eng, track4min, pool):
     print(f"\nconfigs[3] union composite 1920x1080: GPU == oracle on its own vertices for all {len(picks)} frames; against "
           f"the oracle's own chain {int(np.count_nonzero(ndiff))} frames differ, worst {int(ndiff.max())} pixels, "
           f"min PSNR {ps.min():.1f} dB")
-    assert ps.min() >= 50.0 and ndiff.max() <= 24
+    assert ps.min() >= 50.0 and ndiff.max() <= 4          # measured: 0 of 48 frames differ
 
 
 def _ulps(a, b):

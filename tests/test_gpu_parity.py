@@ -17,6 +17,7 @@ import pytest
 from conftest import REPO, golden_analysis_names, load_golden
 from oracle import analysis_ref as A
 from oracle import raster_ref as R
+from aurora_amd.engine import mode_kind as engine_mode_kind
 
 pytestmark = pytest.mark.gpu
 
@@ -1315,6 +1316,64 @@ def test_render_time_duck_type_equals_stream(eng, mode):
     fr = slow.render_time(70 / fps)
     assert fr.shape == (H, W, 3) and fr.tobytes() == buf.getvalue()[70 * W * H * 3:71 * W * H * 3]
     assert slow.render_time(3 / fps).tobytes() == buf.getvalue()[3 * W * H * 3:4 * W * H * 3]
+
+
+@pytest.mark.parametrize("mode", ["Spectrum - Linear", "Spectrum - Radial", "Waveform - Linear", "Waveform - Circular"])
+def test_render_time_call_by_call_is_the_reference_state_machine(eng, mode):
+    """`render_time(t)` for a `t` off the frame grid (export/exporter.py:227-238 reads at int(t * sr) for ANY t and
+    advances the renderer's state by one step per call).  Two checks:
+    (a) the call-by-call path driven with t = i / fps, i = 0, 1, ... produces the bytes of the batched export -- the
+        state machine and the batch are the same function of the call sequence (ring EMA of the radial mode included);
+    (b) an irregular sequence of times (forwards, backwards, repeated, past the end) against the oracle stepped the same
+        way: AnalyzerRef + read_frame + the colour / phase recurrences, frames from the oracle rasteriser fed the GPU's
+        own spectrum of that step (bit-exact), the spectrum itself within the north star's tolerance."""
+    from aurora_amd import synth
+    from aurora_amd.export.exporter import HipOffscreenRenderer
+    from oracle import radial_ref as RR
+    W, H, sr, fps, sens = 320, 192, 44100, 30, 1.3
+    audio = synth.pink(sr * 2 + 311, 2, seed=29)
+    vs = {"hip_batch_frames": 16, "radial_temporal_smoothing": 60}
+    r = HipOffscreenRenderer(W, H, mode, (0.2, 0.8, 1.0), sens, fps, (audio, sr), **vs)
+    # (a)
+    batch = r._pipe.render_device().cpu().numpy()
+    s = HipOffscreenRenderer(W, H, mode, (0.2, 0.8, 1.0), sens, fps, (audio, sr), **vs)
+    for i in range(24):
+        got = s.render_time(i / fps, stepwise=True)
+        assert got.shape == (H, W, 3) and np.array_equal(got, batch[i]), (mode, i, int(np.sum(got != batch[i])))
+    # (b)
+    times = [0.0131, 0.0131, 0.5, 0.4999, 1.23456, 0.02, 1.9, 2.0069, 2.5, 0.7071]
+    q = HipOffscreenRenderer(W, H, mode, (0.2, 0.8, 1.0), sens, fps, (audio, sr), **vs)
+    assert all(abs(t * fps - round(t * fps)) > 1e-6 for t in times if t not in (0.5, 1.9, 2.5))
+    ana = A.AnalyzerRef(sr, 2048)
+    hop = max(1, int(sr / fps))
+    energies, frames, specs, samples = [], [], [], []
+    for t in times:
+        frames.append(q.render_time(t, stepwise=True if t in (0.5, 1.9, 2.5) else None))
+        pos = int(max(0, min(len(audio) - 1, t * sr)))                       # exporter.py:230
+        x = A.read_frame(audio, pos, hop)
+        spec, _ = ana.compute(x)
+        specs.append(spec)
+        samples.append(x)
+        energies.append(A.frame_energy(x, sens))
+    pen, _ = A.amp_to_color_track(np.asarray(energies))
+    phase = A.phase_track(np.asarray(energies))
+    assert q._stepper["state"][2] == phase[-1]                              # phase accumulator, bit for bit
+    kind = engine_mode_kind(mode)
+    ring = RR.RadialTrack(RR.RadialParams.from_view_state(vs, sens)) if kind == "spectrum_radial" else None
+    for k, t in enumerate(times):
+        if kind in ("spectrum_linear", "waveform_linear"):
+            want = R.render_frame(mode, samples[k], specs[k], energies[k], pen[k], W, H)
+            d = int(np.sum(np.any(frames[k] != want, axis=2)))
+            assert d <= 4, (mode, k, t, d)            # a bar top may move by a row on the spectrum's last ulp
+        elif kind == "waveform_circular":
+            path = RR.wave_circular_path(samples[k], energies[k], W, H)
+            assert np.array_equal(frames[k], R.render_wave_circular_frame(path, pen[k], W, H)), (k, t)
+        else:
+            path = ring.path(specs[k], energies[k], W, H)
+            env = RR.envelope_path(specs[k], energies[k], float(phase[k]), W, H, ring.p)
+            want = R.render_radial_frame(path, env, pen[k], W, H)
+            d = int(np.sum(np.any(frames[k] != want, axis=2)))
+            assert d <= 6, (mode, k, t, d)            # edge pixels on last-ulp vertex differences
 
 
 @pytest.mark.parametrize("size,offset16", [((640, 368), 0), ((1280, 720), 7), ((3840, 96), 0), ((96, 40), 3)])

@@ -3,6 +3,12 @@
 Two calls in a row on one GPU, the second with a smaller input: the static work area keeps the first call's contents,
 so the second call's frames show whether anything stale is read.  Bar: byte-identical (integer / byte work).
 Collected last (file name) so a failure here cannot hide another test under `pytest -x`.
+
+Why comparing two HIP entry points is enough here: `aur_raster_spans_ws` is itself pinned to the definition --
+`test_linear_fill_equals_tile_fill` and the raster tests of tests/test_gpu_parity.py hold it bit-exact against the numpy
+oracle (oracle/raster_ref.py) over sizes, span counts and random spans -- and the static entry point runs the very same
+kernels on the very same arguments except for where the work area lives.  What this file has to show is that the place
+makes no difference: stale contents, the size limit, and calls that would overlap on one GPU.
 """
 import ctypes as C
 
@@ -72,3 +78,41 @@ def test_static_work_area_limit():
     # rejected before anything is launched: the pointers are never dereferenced
     rc = lib.aur_raster_spans_static(h, C.c_void_p(4096), 2, C.c_void_p(4096), 149, 3840, 2160, C.c_void_p(4096), None)
     assert rc == -1 and b"static" in lib.aur_last_error() and b"148" in lib.aur_last_error()
+
+
+def test_static_work_area_refuses_a_call_that_would_overlap_on_another_stream():
+    """Every call on a GPU shares that GPU's work area.  A call on another stream while the previous one has not finished
+    is refused (AUR_EINVAL naming both streams) instead of racing; once the first has finished -- or on the same stream,
+    which orders the two -- the call goes through and its frames are right."""
+    import torch
+    from aurora_amd.engine import get_engine
+    eng = get_engine(0)
+    lib, h = eng.lib, eng.ctx.handle
+    rng = np.random.default_rng(77)
+    K, F, W, H = 2, 8, 1280, 360
+    sp = _random_spans(rng, F, K, W, H)
+    spans = torch.from_numpy(sp.view(np.int32)).to(eng.device)
+    pen = torch.from_numpy(rng.integers(0, 256, size=(F, 4), dtype=np.uint8)).to(eng.device)
+    pen[:, 3] = 0
+    want = eng.fill(spans, K, pen, W, H)
+    a, b = torch.cuda.Stream(device=eng.device), torch.cuda.Stream(device=eng.device)
+    got_a = torch.zeros((F, H, W, 3), dtype=torch.uint8, device=eng.device)
+    got_b = torch.zeros_like(got_a)
+    torch.cuda.synchronize()
+
+    def call(stream, out):
+        return lib.aur_raster_spans_static(h, C.c_void_p(spans.data_ptr()), K, C.c_void_p(pen.data_ptr()), F, W, H,
+                                           C.c_void_p(out.data_ptr()), C.c_void_p(stream.cuda_stream))
+
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(400_000_000)                 # keeps stream a busy for a fraction of a second
+    assert call(a, got_a) == 0, lib.aur_last_error()   # queued behind the sleep: not finished when the next call arrives
+    rc = call(b, got_b)
+    msg = lib.aur_last_error().decode()
+    assert rc == -1 and "another stream" in msg, (rc, msg)
+    assert f"{a.cuda_stream:x}" in msg.lower() and f"{b.cuda_stream:x}" in msg.lower(), msg
+    assert call(a, got_a) == 0                         # the same stream is always fine: the stream orders the calls
+    torch.cuda.synchronize()
+    assert call(b, got_b) == 0, lib.aur_last_error()   # the previous call has finished: another stream may use the area
+    torch.cuda.synchronize()
+    assert torch.equal(got_a, want) and torch.equal(got_b, want)

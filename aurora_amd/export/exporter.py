@@ -636,6 +636,12 @@ class Exporter:
         renderer = self.make_renderer()
         logger.info("Export using HIP renderer on MI355X (device %s)", self.view_state.get("hip_device", 0))
         wire = getattr(renderer, "wire_format", "rgb24")
+        if self.view_state.get("hip_segment") and renderer.frame_end <= renderer.frame_begin:
+            # a time shard with no frames (more GPUs than frames): FFmpeg fails on an empty rawvideo input, and the
+            # supervisor's join skips segments that do not exist
+            if progress_cb:
+                progress_cb(100)
+            return None
         if self.view_state.get("hip_segment"):           # one shard of a multi-GPU export: video-only segment
             cmd, _ = build_ffmpeg_segment_cmd(self.width, self.height, self.fps, out_path, prefer_hevc=self.prefer_hevc,
                                               gpu_device=self.gpu_device, input_pix_fmt=wire)

@@ -30,6 +30,7 @@ import hashlib
 import json
 import os
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
@@ -108,8 +109,10 @@ class _Child:
         self.error = None
         self.done = False
         self._on_progress = on_progress
+        # its own session = its own process group: stopping a worker also stops the FFmpeg it started
         self.proc = subprocess.Popen(list(worker_cmd) + [self.cfg_path], stdout=subprocess.PIPE,
-                                     stderr=subprocess.PIPE, env=_child_env(), cwd=_repo_root())
+                                     stderr=subprocess.PIPE, env=_child_env(), cwd=_repo_root(),
+                                     start_new_session=True)
         self._err_tail = []
         self._threads = [threading.Thread(target=self._read_stdout, daemon=True),
                          threading.Thread(target=self._read_stderr, daemon=True)]
@@ -149,8 +152,20 @@ class _Child:
         return f"{self.tag}: {self.error or 'worker exited with status %d' % code}" + (f"\n{tail}" if tail else "")
 
     def stop(self):
+        """Ends the worker AND what it started (its FFmpeg would otherwise go on writing the segment the supervisor is
+        about to remove)."""
         if self.proc.poll() is None:
-            self.proc.terminate()
+            try:
+                os.killpg(self.proc.pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError, AttributeError):
+                self.proc.terminate()
+
+    def reap_group(self):
+        """After the worker has gone: nothing of its process group may be left behind (an FFmpeg that outlived it)."""
+        try:
+            os.killpg(self.proc.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError, AttributeError):
+            pass
 
 
 def _run_children(children):
@@ -249,8 +264,10 @@ def export_sharded(cfg: dict, world: int, progress_cb=None, worker_cmd=None, dev
     with tempfile.TemporaryDirectory(prefix="aurora_shards_") as tmp:
         for r, c in enumerate(children_cfg):                          # all children start before anything else happens
             children.append(_Child(c, tmp, f"shard{r:03d}", worker_cmd or default_worker_cmd(), on_progress))
-        failures = _run_children(children)
+        failures = _run_children(children)           # returns when every worker has been waited for
     if failures:
+        for ch in children:
+            ch.reap_group()
         if not keep_segments:                      # no half-written segments left behind
             for c in children_cfg:
                 seg = c["hip_raw_out"] if cfg.get("hip_raw_out") else c["out_path"]
@@ -263,7 +280,10 @@ def export_sharded(cfg: dict, world: int, progress_cb=None, worker_cmd=None, dev
         segs = [c["hip_raw_out"] for c in children_cfg]
         report = join_raw_segments(segs, str(cfg["hip_raw_out"]), keep_segments)
     else:
-        segs = [c["out_path"] for c in children_cfg]
+        # a shard with no frames (more GPUs than frames) starts no FFmpeg and leaves no segment
+        segs = [c["out_path"] for c in children_cfg if os.path.exists(c["out_path"])]
+        if not segs:
+            raise RuntimeError("sharded export failed: no shard produced a segment (empty track?)")
         join_encoded_segments(segs, cfg["audio_path"], _with_ext(str(cfg["out_path"])), keep_segments)
         report = [(p, None, None) for p in segs]
     if progress_cb is not None:

@@ -149,9 +149,34 @@ def device_numa(bus_id: str, sysfs: str = "/sys/bus/pci/devices"):
     return (node if node >= 0 else None), cpus
 
 
+def _bind_other_threads(cpus) -> int:
+    """Applies the affinity mask to the process's other threads; returns how many took it (a thread may exit meanwhile)."""
+    n = 0
+    import threading
+    me = threading.get_native_id()
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except (OSError, ValueError):
+        return 0
+    for tid in tids:
+        if tid == me:
+            continue
+        try:
+            os.sched_setaffinity(tid, cpus)
+            n += 1
+        except OSError:
+            pass
+    return n
+
+
 def bind_near_device(lib, device: int, sysfs: str = "/sys/bus/pci/devices"):
-    """Restricts the calling process to the CPUs next to HIP device ``device`` (those it is allowed to use anyway).
-    Returns a dict describing what was done; never raises: a host that does not expose the topology is left alone."""
+    """Restricts EVERY thread of the calling process to the CPUs next to HIP device ``device`` (those it is allowed to
+    use anyway).  Asking for the device's PCI address initialises the HIP runtime, and callers have usually set the device
+    or started a process group by then, so helper threads (HIP, RCCL, torch) already exist: ``sched_setaffinity(0, ..)``
+    would bind the calling thread only, so the mask is applied to every task under ``/proc/self/task``; threads started
+    later inherit it from their creator.  What was allocated before the call stays where it is -- call this before the
+    pinned frame ring is allocated (the workers and ``bench.py`` do).  Returns a dict describing what was done; never
+    raises: a host that does not expose the topology is left alone."""
     import ctypes as C
     info = {"device": int(device), "bus_id": None, "numa_node": None, "bound_cpus": 0}
     buf = C.create_string_buffer(64)
@@ -170,6 +195,7 @@ def bind_near_device(lib, device: int, sysfs: str = "/sys/bus/pci/devices"):
         want = allowed & cpus
         if want and want != allowed:
             os.sched_setaffinity(0, want)
+            info["bound_threads"] = 1 + _bind_other_threads(want)
         info["bound_cpus"] = len(want)
     except OSError:
         pass

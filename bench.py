@@ -68,6 +68,8 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=240, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-cores CPU figure (0 = box share)")
     ap.add_argument("--yuv-leg", type=int, default=1, help="also time one export step in the opt-in yuv420p wire format")
+    ap.add_argument("--events", type=int, default=1,
+                    help="0: record no HIP events around the device leg's kernels (counter passes: tools/pmc_passes.sh)")
     ap.add_argument("--pipe-frames", type=int, default=960,
                     help="frames of the pipe leg: the same export through the product's pipe sink into a child process "
                          "that reads stdin as FFmpeg does (0 = skip)")
@@ -385,7 +387,7 @@ def main():
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.device_steps):
-            step(ev_f, ev_s)
+            step(ev_f, ev_s) if args.events else step()
         barrier()
         ddt = sharding.max_over_ranks(time.perf_counter() - t1, device if backend == "nccl" else None)
         roof_dev = kernel_stats(ev_f, frame_bytes)
@@ -428,16 +430,24 @@ def main():
 
     if roof is not None:
         lin = W % 16 == 0 and os.environ.get("AUR_FILL_MODE", "0") != "1"
-        roof["kernel"] = ("raster_fill_rows_kernel + raster_patch_planes_kernel (aur_raster_planes, both passes)"
-                          if planes_mode and W % 32 == 0 and lin else "raster_fill_planes_kernel" if planes_mode else
-                          f"raster_fill_lin_kernel<{K}>" if lin else f"raster_fill16_kernel<{K}>")
+        if planes_mode:
+            # the label follows the path the device leg took (the events bracket that call): without decorations the
+            # engine paints the stroke straight into the frames, with them it goes through the stroke plane
+            direct = eng._direct_stroke_ok(W, H, DB if args.device_steps > 0 else B, eng.empty((1, 16, 64, 3), torch.uint8),
+                                           bool(args.glow))
+            roof["kernel"] = ("raster_fill_rows_kernel + paint_stroke_closed_kernel (aur_raster_closed_path)" if direct else
+                              "raster_fill_rows_kernel + raster_patch_planes_kernel (aur_raster_planes, both passes)"
+                              if W % 32 == 0 and lin else "raster_fill_planes_kernel")
+        else:
+            roof["kernel"] = f"raster_fill_lin_kernel<{K}>" if lin else f"raster_fill16_kernel<{K}>"
     try:                                               # per-launch HBM bytes from separate --pmc passes, if collected
         with open(args.traffic_json) as fh:
             tj = json.load(fh)
         rf = tj.get("raster_fill", {})
         if roof is not None and not planes_mode and rf.get("config") == f"{W}x{H}" and rf.get("hbm_bytes_per_launch"):
-            # collected on 128-frame launches (rocprofv3's counter mode does not survive more dispatches per process
-            # here); the fill's traffic is linear in the frames of a launch
+            # per-launch bytes from tools/pmc_passes.sh (counters for the named kernels only: instrumenting all ~10 000
+            # dispatches of the device leg faults inside rocprofv3's own intercept, profiles/r03_pmc_fault_probe.txt);
+            # the fill's traffic is linear in the frames of a launch, so it is scaled to this run's launch size
             roof["traffic"] = int(round(rf["hbm_bytes_per_launch"] * roof["frames_per_launch"] / rf["frames_per_launch"]))
         if roof_stft is not None and tj.get("stft", {}).get("frames") == roof_stft["frames_per_launch"]:
             roof_stft["traffic"] = tj["stft"]["hbm_bytes_per_launch"]

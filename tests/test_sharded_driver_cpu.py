@@ -27,8 +27,15 @@ FAKE_WORKER = textwrap.dedent('''
         print(json.dumps({"type": "error", "message": "boom on rank %d" % rank}), flush=True)
         sys.exit(1)
     if cfg.get("fake_hang_rank") == rank:
+        if cfg.get("fake_grandchild"):            # the worker's FFmpeg: must not outlive a stopped worker
+            import subprocess
+            g = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"])
+            open(cfg["fake_grandchild"], "w").write(str(g.pid))
         time.sleep(600)
     out = cfg.get("hip_raw_out") or cfg["out_path"]
+    if a == b and vs.get("hip_segment"):          # the product starts no FFmpeg for a shard without frames
+        print(json.dumps({"type": "done"}), flush=True)
+        sys.exit(0)
     with open(out, "wb") as fh:
         for f in range(a, b):
             fh.write(bytes([f % 251]) * fb)
@@ -138,6 +145,60 @@ def test_a_failing_shard_stops_the_others(tmp_path, fake_worker):
     assert not list(tmp_path.glob("frames.seg*.rgb"))                   # rank 0 finished its segment: not left behind
 
 
+def test_stopping_a_worker_stops_what_it_started(tmp_path, fake_worker):
+    """A failing shard ends the others AND their children (a worker's FFmpeg must not go on writing a segment the
+    supervisor removes): workers run in their own process group and the group is signalled."""
+    import time
+    pidfile = tmp_path / "grandchild.pid"
+    cfg = _cfg(tmp_path, hip_raw_out=str(tmp_path / "frames.rgb"), fake_fail_rank=1, fake_hang_rank=2,
+               fake_grandchild=str(pidfile))
+
+    # rank 1 fails only after rank 2 has started its grandchild
+    def slow_fail_worker():
+        p = tmp_path / "slow_fail_worker.py"
+        p.write_text("import json, os, sys, time\ncfg = json.load(open(sys.argv[1]))\n"
+                     "r = (cfg.get('view_state') or {}).get('hip_shard', [0, 1])[0]\n"
+                     "if r == 1:\n"
+                     "    t0 = time.time()\n"
+                     "    while not os.path.exists(cfg['fake_grandchild']) and time.time() - t0 < 30: time.sleep(0.05)\n"
+                     "    time.sleep(0.2)\n"
+                     f"exec(open({str(tmp_path / 'fake_worker.py')!r}).read())\n")
+        return [sys.executable, str(p)]
+
+    with pytest.raises(RuntimeError):
+        sharded.export_sharded(cfg, 3, None, worker_cmd=slow_fail_worker(), devices=[0])
+    pid = int(pidfile.read_text())
+    for _ in range(100):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        # a zombie re-parented to init still answers kill(0) until it is reaped: look at its state
+        try:
+            if open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] == "Z":
+                break
+        except OSError:
+            break
+        time.sleep(0.05)
+    else:
+        os.kill(pid, 9)
+        raise AssertionError("the stopped worker's child is still running")
+
+
+def test_more_gpus_than_frames(tmp_path, fake_worker, monkeypatch):
+    """Shards with an empty frame range: a raw segment of zero bytes joins as nothing; an encoded shard starts no FFmpeg
+    and leaves no segment, and the concat join takes the segments that exist."""
+    raw = tmp_path / "frames.rgb"
+    sharded.export_sharded(_cfg(tmp_path, 3, 8, hip_raw_out=str(raw)), 8, None, worker_cmd=fake_worker, devices=[0])
+    assert raw.read_bytes() == _expected(3, 8)
+    ff = tmp_path / "ffmpeg"
+    ff.write_text(FAKE_FFMPEG)
+    ff.chmod(ff.stat().st_mode | stat.S_IXUSR)
+    monkeypatch.setenv("AURORA_FFMPEG", str(ff))
+    sharded.export_sharded(_cfg(tmp_path, 3, 8), 8, None, worker_cmd=fake_worker, devices=[0])
+    assert (tmp_path / "out.mp4").read_bytes() == _expected(3, 8)
+
+
 def test_many_tracks_are_dealt_over_gpu_lanes(tmp_path, fake_worker):
     cfgs = [_cfg(tmp_path, 10 + k, 4, hip_raw_out=str(tmp_path / f"t{k}.rgb")) for k in range(7)]
     seen = []
@@ -191,13 +252,23 @@ def test_numa_placement_helpers(tmp_path):
             buf.value = self.bus
             return 0
 
+    import threading
     before = os.sched_getaffinity(0)
+    stop = threading.Event()
+    helper = threading.Thread(target=stop.wait, daemon=True)
+    helper.start()
     try:
         info = sharding.bind_near_device(_Lib(b"0000:c1:00.0"), 3, str(tmp_path))
-        assert info == {"device": 3, "bus_id": "0000:c1:00.0", "numa_node": 1, "bound_cpus": 1}
+        assert {k: info[k] for k in ("device", "bus_id", "numa_node", "bound_cpus")} == \
+            {"device": 3, "bus_id": "0000:c1:00.0", "numa_node": 1, "bound_cpus": 1}
         assert os.sched_getaffinity(0) == {allowed[0]}
+        if len(allowed) > 1:
+            # threads that existed before the call are bound too (HIP / RCCL helper threads in a real rank)
+            assert info["bound_threads"] >= 2 and os.sched_getaffinity(helper.native_id) == {allowed[0]}
     finally:
         os.sched_setaffinity(0, before)
+        sharding._bind_other_threads(before)
+        stop.set()
     (dev / "numa_node").write_text("-1\n")                      # virtual machines
     assert sharding.bind_near_device(_Lib(b"0000:c1:00.0"), 0, str(tmp_path))["bound_cpus"] == 0
     assert os.sched_getaffinity(0) == before

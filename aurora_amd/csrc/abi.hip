@@ -91,6 +91,8 @@ extern "C" int aur_create(int device, aur_ctx** out) {
     if (const char* e = getenv("AUR_FILL_ROWS")) ctx->fill_rows = atoi(e);
     if (const char* e = getenv("AUR_FILL_NT")) ctx->fill_nt = atoi(e);
     if (const char* e = getenv("AUR_FILL_MODE")) ctx->fill_mode = atoi(e);
+    ctx->stft_zt = 1;
+    if (const char* e = getenv("AUR_STFT_ZT")) ctx->stft_zt = atoi(e);
     if (const char* e = getenv("AUR_STFT_FPW")) ctx->stft_fpw = atoi(e);
     double h_tw[AUR_TW_DOUBLES];
     build_tables(ctx->h_window, h_tw);

@@ -36,6 +36,7 @@ struct aur_ctx {
     // tuning knobs, read once from the environment in aur_create (0 = built-in default)
     int fill_rows;         // AUR_FILL_ROWS: rows per wave task of the fill kernel
     int fill_nt;           // AUR_FILL_NT=1: non-temporal frame stores
+    int stft_zt;           // AUR_STFT_ZT=0: hop <= 896 keeps the general STFT kernel instead of the zero-tail variant (A/B runs)
     int fill_mode;         // AUR_FILL_MODE=1: aur_raster_spans_ws / aur_raster_planes use the row-tile kernels (A/B runs)
     int stft_fpw;          // AUR_STFT_FPW: frames per wave of the STFT kernel
     void* d_static_work;   // this device's address of raster.hip's file-scope work area (aur_raster_spans_static)

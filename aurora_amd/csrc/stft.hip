@@ -107,13 +107,26 @@ __device__ __forceinline__ void radix4(cd& x0, cd& x1, cd& x2, cd& x3) {
     x3 = csub(t1, t3);
 }
 
+// the same butterfly when x1 and x3 are known to be zero (the zero tail of a short hop, see ZT below): two complex
+// additions instead of eight
+__device__ __forceinline__ void radix4_z13(cd& x0, cd& x1, cd& x2, cd& x3) {
+    const cd t0 = cadd(x0, x2), t1 = csub(x0, x2);
+    x0 = t0;
+    x1 = t1;
+    x2 = t0;
+    x3 = t1;
+}
+
 // In-register 16-point forward DFT.  Input v[j], j = 4a + b.  Output X[k], k = c + 4d, is left in v[4c + d].
+// ZT: inputs v[7] and v[15] are zero (pass 1 of a frame whose blocks end in at least 128 zeros).
+template <bool ZT = false>
 __device__ __forceinline__ void dft16(cd (&v)[16]) {
     constexpr double C1 = 0.92387953251128673848;   // cos(pi/8)
     constexpr double S1 = 0.38268343236508978178;   // sin(pi/8)
     constexpr double H = 0.70710678118654752440;    // sqrt(1/2)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) radix4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    for (int b = 0; b < (ZT ? 3 : 4); ++b) radix4(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    if (ZT) radix4_z13(v[3], v[7], v[11], v[15]);
     // now v[4c + b] = T[b][c]; multiply by W16^(b c)
     v[4 * 1 + 1] = cmul(v[4 * 1 + 1], cd{C1, -S1});                                  // W^1
     v[4 * 2 + 1] = cd{H * (v[4 * 2 + 1].x + v[4 * 2 + 1].y), H * (v[4 * 2 + 1].y - v[4 * 2 + 1].x)};   // W^2
@@ -164,9 +177,15 @@ __device__ __forceinline__ float wave_max_pos(float v) {
 constexpr int kRsrcWord3 = 0x00020000;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Two float32 values in a register pair: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 work on both at once.  The file is
+// built without the SLP vectoriser (Makefile): left to itself it packs scalar float32 arithmetic whose operands sit in
+// unrelated registers and pays two or three v_mov_b32 per packed instruction to line them up (measured: 97 moves per
+// frame, 1118 -> 1103 VALU instructions with it off).  What is packed here is packed by type, with the pairs laid out
+// the same way from the load to the last use: a block is v2f[8], element jj = samples (2 lane + 128 jj, + 1).
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // One 1024-sample analysis block of frame `fi` (exporter.py:230-237) in the lane layout of the FFT:
-// blk[2jj], blk[2jj+1] = samples[2*lane + 128*jj], samples[2*lane + 128*jj + 1].
+// blk[jj] = (samples[2*lane + 128*jj], samples[2*lane + 128*jj + 1]).
 // Two phases, so that the loads can fly while another frame is being transformed: issue_block requests the raw
 // interleaved samples, mix_block (mono mean) is the first thing that waits for them.
 template <int C>
@@ -180,7 +199,15 @@ struct RawBlock {
 // whole block in front of the track start (fi < 0: Analyzer.buffer is zero, analysis.py:14) -- is then out of range and
 // loads as 0 without a compare, a select or a clamped address in the vector ALU: the resource is four scalar registers
 // built by the scalar ALU from the wave-uniform pos[fi].  Eight unconditional loads of two samples each.
-template <int C>
+// DEPENDENCY: the per-jj step (128 jj samples) travels in the instruction's soffset operand, and the zero padding relies
+// on the range check covering voffset + soffset.  gfx950 (like the rest of the GFX9 family, raw buffers, no swizzle)
+// checks `offset = voffset + inst_offset + soffset` against num_records; LLVM's builtin documentation calls soffset
+// "excluded from bounds checking" for the sake of other generations.  tests/test_gpu_parity.py::
+// test_zero_padding_is_the_buffer_range_check pins the behaviour directly (a track of non-zero samples, with non-zero
+// memory behind its end): a toolchain or part that drops the check fails there, loudly.
+// ZT (zero tail): the caller knows hop <= 896, so samples 896..1023 of every block (jj = 7 in every lane) are padding:
+// they are neither loaded nor mixed nor windowed, and pass 1 of the FFT drops them from its first butterflies.
+template <int C, bool ZT>
 __device__ __forceinline__ void issue_block(const float* __restrict__ audio, long n_samp,
                                             const long* __restrict__ pos, long fi, int hop, int lane,
                                             RawBlock<C>& raw) {
@@ -194,7 +221,7 @@ __device__ __forceinline__ void issue_block(const float* __restrict__ audio, lon
         __builtin_amdgcn_make_buffer_rsrc((void*)(audio + p * C), 0, (int)(nv * (unsigned)(C * 4)), kRsrcWord3);
     const int voff = lane * (2 * C * 4);
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
+    for (int jj = 0; jj < (ZT ? 7 : 8); ++jj) {
         if (C == 2) {
             const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 128 * jj * C * 4, 0);   // (L0, R0, L1, R1)
             raw.q[jj][0] = __uint_as_float(q.x);
@@ -209,27 +236,31 @@ __device__ __forceinline__ void issue_block(const float* __restrict__ audio, lon
     }
 }
 
-template <int C>
-__device__ __forceinline__ void mix_block(const RawBlock<C>& raw, float (&blk)[16]) {
+template <int C, bool ZT>
+__device__ __forceinline__ void mix_block(const RawBlock<C>& raw, v2f (&blk)[8]) {
+    if (ZT) blk[7] = v2f{0.0f, 0.0f};
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-        // y.mean(axis=1) in float32: (L + R) rounded, then * 0.5 (exporter.py:234); padding zeros stay zero
-        blk[2 * jj] = (C == 2) ? (raw.q[jj][0] + raw.q[jj][1]) * 0.5f : raw.q[jj][0];
-        blk[2 * jj + 1] = (C == 2) ? (raw.q[jj][2 * C - 2] + raw.q[jj][2 * C - 1]) * 0.5f : raw.q[jj][2 * C - 1];
+    for (int jj = 0; jj < (ZT ? 7 : 8); ++jj) {
+        // y.mean(axis=1) in float32: (L + R) rounded, then * 0.5 (exporter.py:234); padding zeros stay zero.
+        // Two scalar additions into a register pair, one packed multiplication.
+        if (C == 2)
+            blk[jj] = v2f{raw.q[jj][0] + raw.q[jj][1], raw.q[jj][2 * C - 2] + raw.q[jj][2 * C - 1]} * 0.5f;
+        else
+            blk[jj] = v2f{raw.q[jj][0], raw.q[jj][2 * C - 1]};
     }
 }
 
-template <int C>
+template <int C, bool ZT>
 __device__ __forceinline__ void load_block(const float* __restrict__ audio, long n_samp,
                                            const long* __restrict__ pos, long fi, int hop, int lane,
-                                           float (&blk)[16]) {
+                                           v2f (&blk)[8]) {
     RawBlock<C> raw;
-    issue_block<C>(audio, n_samp, pos, fi, hop, lane, raw);
-    mix_block<C>(raw, blk);
+    issue_block<C, ZT>(audio, n_samp, pos, fi, hop, lane, raw);
+    mix_block<C, ZT>(raw, blk);
 }
 
 struct Tables {
-    const float2* win;   // LDS: (w[2n], w[2n+1]), n < 1024
+    const v2f* win;      // LDS: (w[2n], w[2n+1]), n < 1024
     const cd* tw2;       // LDS: W64^(r q), [r][q]
     const cd* tw1;       // LDS: &W1024^(lane k1)[k1 - 1][lane]; rows are 64 complex doubles (ds_read_b128, lane-linear)
     cd wuh;              // 0.5 * W2048^lane
@@ -249,7 +280,7 @@ __device__ __forceinline__ Tables stage_tables(const float* __restrict__ window,
     double* t2 = reinterpret_cast<double*>(smem + kLdsWinBytes);
     for (int i = threadIdx.x; i < 128; i += blockDim.x) t2[2 * kTw2Stride * (i >> 5) + (i & 31)] = twid[AUR_TW_W2 + i];
     Tables t;
-    t.win = reinterpret_cast<const float2*>(smem);
+    t.win = reinterpret_cast<const v2f*>(smem);
     t.tw2 = reinterpret_cast<const cd*>(t2);
     double2* t1 = reinterpret_cast<double2*>(smem + kLdsWinBytes + kLdsTw2Bytes);
     const double2* t1src = reinterpret_cast<const double2*>(twid + AUR_TW_P1);
@@ -270,28 +301,28 @@ __device__ __forceinline__ Tables stage_tables(const float* __restrict__ window,
 
 // mean(|samples|) of one block in numpy's pairwise order (8 blocks of 128, 8 strided accumulators each, then
 // the fixed add tree); `xf` is the wave's exchange buffer.  Returns the mean in every lane.
-__device__ __forceinline__ float block_meanabs(const float (&cur)[16], int lane, float* xf) {
+__device__ __forceinline__ float block_meanabs(const v2f (&cur)[8], int lane, float* xf) {
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-        float2 a = {fabsf(cur[2 * jj]), fabsf(cur[2 * jj + 1])};
-        *reinterpret_cast<float2*>(xf + 2 * lane + 136 * jj) = a;   // element i lives at i + 8 * (i / 128)
-    }
+    for (int jj = 0; jj < 8; ++jj)
+        *reinterpret_cast<v2f*>(xf + 2 * lane + 136 * jj) = cur[jj];   // element i lives at i + 8 * (i / 128)
     wave_sync();
+    // |x| is taken where the value is added: a source modifier of v_add_f32 instead of 16 v_and_b32 in front of the stores
     const float* e = xf + 136 * (lane >> 3) + (lane & 7);
-    float r = e[0];
+    float r = fabsf(e[0]);
 #pragma unroll
-    for (int t = 1; t < 16; ++t) r += e[8 * t];
+    for (int t = 1; t < 16; ++t) r += fabsf(e[8 * t]);
     r = wave_sum(r);
     wave_sync();
     return r * (1.0f / 1024.0f);
 }
 
 // 1024-point complex FFT (float64) of the windowed, packed 2048-sample buffer [prv | cur].
-// In: prv/cur[2jj], [2jj+1] = block samples 2*lane + 128*jj, +1.
+// In: prv/cur[jj] = block samples (2*lane + 128*jj, +1).
 // Out (slot p = 4 ql + s, ql < 2, s < 4):  v[p] = Z[lane + 64 (ql + 4 s)],  v[8 + p] = Z[b_ql + 256 s] with
 // b_0 = 256 - lane, b_1 = 192 - lane, i.e. v[8 + 4 ql + (3 - s)] = Z[1024 - (lane + 64 (ql + 4 s))], the unpack
 // partner of v[p].  Lane 0 (whose bins 64 j pair among themselves) reads b_0 = 128 instead: v[8 + s] = Z[128 + 256 s].
-__device__ __forceinline__ void fft_packed(const float (&prv)[16], const float (&cur)[16], int lane,
+template <bool ZT = false>
+__device__ __forceinline__ void fft_packed(const v2f (&prv)[8], const v2f (&cur)[8], int lane,
                                            const Tables& T, double* xb_, cd (&v)[16]) {
     // volatile: keeps one ds_read_b64 / ds_write_b64 per element.  Merged into ds_read2_b64 / ds_write2_b64 the
     // accesses fall back to 32-bank addressing (half the LDS rate) and the padded rows conflict two ways.
@@ -300,17 +331,18 @@ __device__ __forceinline__ void fft_packed(const float (&prv)[16], const float (
     // window in float32 exactly as the reference (buffer * window, analysis.py:25), then widen and pack:
     // z[l + 64 j] = (x[2n] w[2n], x[2n+1] w[2n+1])
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float2 w = T.win[lane + 64 * j];
-        v[j] = cd{(double)(prv[2 * j] * w.x), (double)(prv[2 * j + 1] * w.y)};
+    for (int j = 0; j < (ZT ? 7 : 8); ++j) {
+        const v2f xw = prv[j] * T.win[lane + 64 * j];
+        v[j] = cd{(double)xw.x, (double)xw.y};
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float2 w = T.win[lane + 64 * (j + 8)];
-        v[j + 8] = cd{(double)(cur[2 * j] * w.x), (double)(cur[2 * j + 1] * w.y)};
+    for (int j = 0; j < (ZT ? 7 : 8); ++j) {
+        const v2f xw = cur[j] * T.win[lane + 64 * (j + 8)];
+        v[j + 8] = cd{(double)xw.x, (double)xw.y};
     }
+    if (ZT) v[7] = v[15] = cd{0.0, 0.0};
     // pass 1: radix-16 over j, twiddle W1024^(l k1), transpose through LDS (rows padded to 66: conflict-free)
-    dft16(v);
+    dft16<ZT>(v);
     // twiddle W1024^(l k1) from the LDS table (one ds_read_b128 per value: the LDS array has cycles to spare, the
     // float64 VALU does not -- building the powers per frame cost 56 of its instructions)
 #pragma unroll
@@ -377,7 +409,7 @@ __device__ __forceinline__ float mag_from_sq(double m2) { return __builtin_amdgc
 __device__ __forceinline__ float log1p_pos(float x) {
     const float u = 1.0f + x;
     const float c = x - (u - 1.0f);
-    return fmaf(c, fmaxf(2.0f - u, 0.0f), __builtin_amdgcn_logf(u) * 0.693147180559945309f);
+    return fmaf(c, fminf(fmaxf(2.0f - u, 0.0f), 1.0f), __builtin_amdgcn_logf(u) * 0.693147180559945309f);   // clamp modifier
 }
 
 // ---- the displayed bins (k < 128; the export only draws spectrum[:80], rt_widget.py:935) in the reference's own chain ----
@@ -432,7 +464,6 @@ __device__ __forceinline__ int slot_bin(int lane, int p) {
     return lane + 64 * (ql + 4 * s) + ((lane == 0 && ql == 0 && s >= 2) ? 128 : 0);
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));     // (bin kA, bin 1024 - kA) of a slot: packed float32 math
 
 struct Mags {
     v2f ab[8];
@@ -458,7 +489,10 @@ struct MagsLds {
 __device__ __forceinline__ v2f log1p_pos2(v2f x) {
     const v2f u = 1.0f + x;
     const v2f c = x - (u - 1.0f);
-    const v2f t = __builtin_elementwise_max(2.0f - u, (v2f)(0.0f));
+    // u >= 1, so 2 - u <= 1 and max(2 - u, 0) is the clamp of 2 - u to [0, 1]: the output modifier of the packed
+    // subtraction (the compiler folds it for the scalar form in log1p_pos, not for v_pk_add_f32: two v_max_f32 per pair)
+    v2f t;
+    asm("v_pk_add_f32 %0, %1, 2.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0] clamp" : "=v"(t) : "v"(u));
     const v2f lg = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
     return __builtin_elementwise_fma(c, t, lg * 0.693147180559945309f);
 }
@@ -573,7 +607,8 @@ __device__ __forceinline__ void mags_store(const Mags& m, float* __restrict__ ds
 }
 
 // LOG: logspec is stored; BM: band maxima are stored; SAMPLES: the mono blocks are stored (waveform mode).
-template <int C, bool LOG, bool BM, bool SAMPLES>
+// ZT: hop <= 896, every block ends in at least 128 zeros (48 kHz at 60 frames/s: hop 800).
+template <int C, bool LOG, bool BM, bool SAMPLES, bool ZT>
 __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stft_frames_kernel(
     const float* __restrict__ audio, long n_samp, const long* __restrict__ pos, long frame_begin, int n_frames,
     int hop, int frames_per_wave, const float* __restrict__ window, const double* __restrict__ twid,
@@ -609,9 +644,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     // Analyzer.buffer starts at zero (analysis.py:14); a chunk that starts inside the track first replays frame
     // c0 - 1 (the halo) to rebuild Analyzer.prev_mag, storing nothing.
     const long fstart = (c0 > 0) ? c0 - 1 : c0;
-    float prv[16], cur[16];
-    load_block<C>(audio, n_samp, pos, fstart - 1, hop, lane, prv);
-    load_block<C>(audio, n_samp, pos, fstart, hop, lane, cur);
+    v2f prv[8], cur[8];
+    load_block<C, ZT>(audio, n_samp, pos, fstart - 1, hop, lane, prv);
+    load_block<C, ZT>(audio, n_samp, pos, fstart, hop, lane, cur);
 
     // One frame.  STORE = false is the halo frame: transform and magnitudes only.  The next frame's block is
     // requested after the FFT, before anything of this frame is stored, and is first touched at the end of the body:
@@ -630,11 +665,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
                     __builtin_amdgcn_make_buffer_rsrc((void*)(samples_out + fo * AUR_BLOCK), 0, AUR_BLOCK * 4, kRsrcWord3);
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj)
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(cur[2 * jj]), __float_as_uint(cur[2 * jj + 1])},
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(cur[jj].x), __float_as_uint(cur[jj].y)},
                                                           srs, 8 * lane + 512 * jj, 0, 0);
             }
         }
-        fft_packed(prv, cur, lane, T, xb, v);
+        fft_packed<ZT>(prv, cur, lane, T, xb, v);
         RawBlock<C> nxt;
         float lg0 = 0.0f, lg1 = 0.0f;
         // the frame's spectrum row as a buffer resource (an empty one when nothing is stored: logspec may be NULL)
@@ -643,7 +678,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
             (void*)(logspec + (row ? fo * AUR_NBINS : 0)), 0, row ? AUR_NBINS * 4 : 0, kRsrcWord3);
         float fl = unpack_mag<STORE && (LOG || BM), STORE && LOG>(
             v, lane, T, pmag, ors, lg0, lg1,
-            [&]() { issue_block<C>(audio, n_samp, pos, (f + 1 < cend) ? f + 1 : -1, hop, lane, nxt); });
+            [&]() { issue_block<C, ZT>(audio, n_samp, pos, (f + 1 < cend) ? f + 1 : -1, hop, lane, nxt); });
         if (STORE) {
             fl = wave_sum(fl);
             if (lane == 0) flux_sum[fo] = fl;
@@ -658,8 +693,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
             }
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) prv[i] = cur[i];
-        mix_block<C>(nxt, cur);
+        for (int i = 0; i < (ZT ? 7 : 8); ++i) prv[i] = cur[i];
+        mix_block<C, ZT>(nxt, cur);
     };
 
     long f = fstart;
@@ -681,17 +716,13 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
     const int lane = threadIdx.x;
     const Tables T = stage_tables(window, twid, smem, lane);
     double* xb = reinterpret_cast<double*>(smem + kLdsTabBytes);
-    float prv[16], cur[16];
+    v2f prv[8], cur[8];
     Mags pmag;
     cd v[16];
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
-        const float2 a = *reinterpret_cast<const float2*>(buffer + 2 * lane + 128 * jj);
-        const float2 b = *reinterpret_cast<const float2*>(buffer + AUR_BLOCK + 2 * lane + 128 * jj);
-        prv[2 * jj] = a.x;
-        prv[2 * jj + 1] = a.y;
-        cur[2 * jj] = b.x;
-        cur[2 * jj + 1] = b.y;
+        prv[jj] = *reinterpret_cast<const v2f*>(buffer + 2 * lane + 128 * jj);
+        cur[jj] = *reinterpret_cast<const v2f*>(buffer + AUR_BLOCK + 2 * lane + 128 * jj);
     }
     mags_load(pmag, prev_mag, lane);
     fft_packed(prv, cur, lane, T, xb, v);
@@ -738,8 +769,8 @@ __global__ __launch_bounds__(256) void mix_channels_kernel(const float* __restri
     mono[i] = res / (float)C;
 }
 
-template <int C, bool LOG, bool BM, bool SAMPLES>
-int launch_stft(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int64_t* d_pos, int64_t frame_begin,
+template <int C, bool LOG, bool BM, bool SAMPLES, bool ZT>
+int launch_stft_z(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int64_t* d_pos, int64_t frame_begin,
                 int n_frames, int hop, float* d_logspec, float* d_flux_sum, float* d_meanabs, float* d_samples,
                 float* d_bandmax, hipStream_t st) {
     // frames per wave: the range is cut into k rounds of one wave per wave slot (2 per SIMD), k as small as keeps a
@@ -752,14 +783,26 @@ int launch_stft(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int
     const long n_waves = ((long)n_frames + fpw - 1) / fpw;
     const unsigned grid = (unsigned)((n_waves + kWavesPerWG - 1) / kWavesPerWG);
     if (kLdsBytes > 64 * 1024) {   // once per instantiation and device would do; the call is cheap
-        AUR_CHECK_HIP(hipFuncSetAttribute((const void*)stft_frames_kernel<C, LOG, BM, SAMPLES>,
+        AUR_CHECK_HIP(hipFuncSetAttribute((const void*)stft_frames_kernel<C, LOG, BM, SAMPLES, ZT>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
-    hipLaunchKernelGGL((stft_frames_kernel<C, LOG, BM, SAMPLES>), dim3(grid), dim3(kWavesPerWG * 64), kLdsBytes, st,
+    hipLaunchKernelGGL((stft_frames_kernel<C, LOG, BM, SAMPLES, ZT>), dim3(grid), dim3(kWavesPerWG * 64), kLdsBytes, st,
                        d_audio, (long)n_samples, (const long*)d_pos, (long)frame_begin, n_frames, hop, fpw,
                        ctx->d_window, ctx->d_twid, d_logspec, d_flux_sum, d_meanabs, d_samples, d_bandmax);
     AUR_CHECK_HIP(hipGetLastError());
     return AUR_OK;
+}
+
+// hop <= 896: the zero-tail variant (AUR_STFT_ZT=0 in the environment keeps the general kernel: A/B runs)
+template <int C, bool LOG, bool BM, bool SAMPLES>
+int launch_stft(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const int64_t* d_pos, int64_t frame_begin,
+                int n_frames, int hop, float* d_logspec, float* d_flux_sum, float* d_meanabs, float* d_samples,
+                float* d_bandmax, hipStream_t st) {
+    if (hop <= AUR_BLOCK - 128 && ctx->stft_zt)
+        return launch_stft_z<C, LOG, BM, SAMPLES, true>(ctx, d_audio, n_samples, d_pos, frame_begin, n_frames, hop,
+                                                        d_logspec, d_flux_sum, d_meanabs, d_samples, d_bandmax, st);
+    return launch_stft_z<C, LOG, BM, SAMPLES, false>(ctx, d_audio, n_samples, d_pos, frame_begin, n_frames, hop,
+                                                     d_logspec, d_flux_sum, d_meanabs, d_samples, d_bandmax, st);
 }
 
 // Which outputs are wanted is a compile-time property of the kernel (no branches in the frame loop).

@@ -1628,3 +1628,35 @@ def test_closed_path_modes_outside_the_direct_entry_points_shapes(eng, tmp_path)
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=200)
     assert res.returncode == 0, res.stderr[-3000:]
     assert json.loads(res.stdout.strip().splitlines()[-1]) == want
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+@pytest.mark.parametrize("hop", [1, 127, 128, 129, 800, 895, 896, 897, 1023, 1024, 1470])
+def test_zero_padding_is_the_buffer_range_check(eng, hop, channels):
+    """The reference pads a frame's block with zeros past `hop` samples and past the end of the file
+    (export/exporter.py:231-237).  The kernel gets those zeros from the buffer resource's range check alone (csrc/stft.hip,
+    issue_block: the per-jj step is the soffset operand), so this test makes every byte the check must hide non-zero:
+    a track of ones, with ones in the allocation BEHIND the declared end of the track as well.  samples[f] must be
+    exactly hop ones (fewer at the end of the file) followed by zeros, through the C ABI."""
+    import ctypes as C
+    import torch
+    n_decl, extra = 5 * hop + 37, 4096
+    buf = torch.ones((n_decl + extra, channels), dtype=torch.float32, device=eng.device)
+    pos_host = np.asarray([0, hop, 2 * hop + 3, n_decl - hop - 1, n_decl - 40, n_decl - 1], dtype=np.int64)
+    pos = torch.from_numpy(pos_host).to(eng.device)
+    F = len(pos_host)
+    logspec = torch.empty((F, 1025), dtype=torch.float32, device=eng.device)
+    flux = torch.empty(F, dtype=torch.float32, device=eng.device)
+    mean = torch.empty(F, dtype=torch.float32, device=eng.device)
+    samples = torch.full((F, 1024), -7.0, dtype=torch.float32, device=eng.device)
+    rc = eng.lib.aur_stft_frames(eng.ctx.handle, C.c_void_p(buf.data_ptr()), n_decl, channels, C.c_void_p(pos.data_ptr()),
+                                 0, F, hop, C.c_void_p(logspec.data_ptr()), C.c_void_p(flux.data_ptr()),
+                                 C.c_void_p(mean.data_ptr()), C.c_void_p(samples.data_ptr()), None, eng.stream())
+    assert rc == 0, eng.lib.aur_last_error()
+    got = samples.cpu().numpy()
+    for f, p in enumerate(pos_host):
+        nv = int(min(hop, 1024, n_decl - p))
+        want = np.zeros(1024, np.float32)
+        want[:nv] = 1.0
+        assert np.array_equal(got[f], want), (hop, channels, f, int(p), nv, int(got[f].sum()))
+    assert np.array_equal(mean.cpu().numpy(), np.asarray([min(hop, 1024, n_decl - p) / 1024 for p in pos_host], np.float32))

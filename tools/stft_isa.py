@@ -11,14 +11,14 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "stft_frames_kernelILi2ELb1ELb0ELb0"      # stereo, log-spectrum stored, no band maxima, no sample output
+KERNEL = os.environ.get("STFT_ISA_KERNEL", "stft_frames_kernelILi2ELb1ELb0ELb0ELb1E")   # stereo, log-spectrum stored, no band maxima, no sample output, zero tail (hop <= 896: the 48 kHz / 60 fps headline)
 
 
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "stft.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
-                               "-fPIC", "--cuda-device-only", "-S", os.path.join(ROOT, "aurora_amd", "csrc", "stft.hip"),
+                               "-fPIC", "-fno-slp-vectorize", "--cuda-device-only", "-S", os.path.join(ROOT, "aurora_amd", "csrc", "stft.hip"),
                                "-o", asm], stderr=subprocess.DEVNULL)
         txt = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "isa_hist.py"), asm, KERNEL, "60"],
                                       text=True)

@@ -52,7 +52,7 @@ namespace {
 #define AUR_STFT_WAVES_PER_WG 4
 #endif
 #ifndef AUR_STFT_MID_AT
-#define AUR_STFT_MID_AT 4              // unpack slot before which the next block's loads are issued: half of v[] is dead there,
+#define AUR_STFT_MID_AT 2              // unpack slot before which the next block's loads are issued: half of v[] is dead there,
                                        // so the 32 load registers cost no extra pressure (0: before the unpack)
 #endif
 #ifndef AUR_STFT_WAVES_PER_CU

@@ -445,9 +445,9 @@ def main():
             tj = json.load(fh)
         rf = tj.get("raster_fill", {})
         if roof is not None and not planes_mode and rf.get("config") == f"{W}x{H}" and rf.get("hbm_bytes_per_launch"):
-            # per-launch bytes from tools/pmc_passes.sh (counters for the named kernels only: instrumenting all ~10 000
-            # dispatches of the device leg faults inside rocprofv3's own intercept, profiles/r03_pmc_fault_probe.txt);
-            # the fill's traffic is linear in the frames of a launch, so it is scaled to this run's launch size
+            # per-launch bytes from tools/pmc_passes.sh, collected on 128-frame launches (one of the dispatch sequences
+            # rocprofv3's counter mode survives here, profiles/r03_pmc_fault_probe.txt); the fill's traffic is linear in
+            # the frames of a launch, so it is scaled to this run's launch size
             roof["traffic"] = int(round(rf["hbm_bytes_per_launch"] * roof["frames_per_launch"] / rf["frames_per_launch"]))
         if roof_stft is not None and tj.get("stft", {}).get("frames") == roof_stft["frames_per_launch"]:
             roof_stft["traffic"] = tj["stft"]["hbm_bytes_per_launch"]

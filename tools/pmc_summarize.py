@@ -56,9 +56,9 @@ def main(root):
             return None
         return int(round(2 * 1024 * c["FETCH_SIZE"]["mean_per_dispatch"] + 1024 * c["WRITE_SIZE"]["mean_per_dispatch"]))
     tj = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `bench.py "
-                    "--seconds 4 --steps 0 --cpu-frames 0 --device-steps 1 --device-warmup 0 --batch 128` (tools/pmc_passes.sh; largest-grid dispatches of each kernel); bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE",
+                    "--seconds 4 --steps 0 --cpu-frames 0 --pipe-frames 0 --device-steps 1 --device-warmup 0 --batch 128` (tools/pmc_passes.sh; largest-grid dispatches of each kernel); bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE",
           "raster_fill": {"config": os.environ.get("AUR_PMC_FILL_CONFIG", "3840x2160"),
-                          "frames_per_launch": int(os.environ.get("AUR_PMC_FILL_FRAMES", "128")),
+                          "frames_per_launch": int(os.environ.get("AUR_PMC_FILL_FRAMES", "64")),
                           "kernel": "raster_fill_lin_kernel",
                           "hbm_bytes_per_launch": traffic("raster_fill_lin_kernel")},
           "stft": {"frames": int(os.environ.get("AUR_PMC_STFT_FRAMES", "216000")),

@@ -16,10 +16,15 @@ if [ "$1" = build ]; then
     f=$d/aurora_amd/csrc/stft.hip
     case $v in
       noexch)  python3 -c "import re,sys; s=open(sys.argv[1]).read(); s=re.sub(r'#pragma unroll\n    for \([^\n]*\) [^\n]*xb\[[^\n]*\n','',s); open(sys.argv[1],'w').write(s)" $f ;;
-      nostore) sed -i '/out_a2\?\[.*\] = la;/d; /out_b2\?\[.*\] = lb;/d' $f ;;
-      nomean)  sed -i 's/const float ma = block_meanabs(cur, lane, xf);/const float ma = cur[0];/' $f ;;
+      nostore) sed -i '/^ *aur_buf_st(l\.[xy], out, /d; s/if (EMIT \&\& STORE_LOG) aur_buf_st(log1p_pos(mm), out, 4 \* 512);/if (EMIT \&\& STORE_LOG \&\& mm < 0.0f) aur_buf_st(mm, out, 2048);/' $f
+               sed -i 's/if (j == 0) lg0 = l.x;/lg0 += l.x + l.y;/' $f ;;
+      nomean)  sed -i 's/const float ma = block_meanabs(cur, lane, xf);/const float ma = cur[0].x;/' $f ;;
+      notw)    sed -i 's/v\[i\] = cmul(v\[i\], T.tw1\[64 \* (k1 - 1)\]);/v[i] = cmul(v[i], T.wuh);/; s/v\[i\] = cmul(v\[i\], T.tw2\[hi2 \* kTw2Stride + q\]);/v[i] = cmul(v[i], T.wus);/' $f ;;
+      nolog)   sed -i 's/const v2f l = j < 2 ? v2f{log1p_cr(m.x, T.lg), log1p_pos(m.y)} : log1p_pos2(m);/const v2f l = m;/' $f ;;
+      nocabs)  sed -i 's/const v2f m = {j < 2 ? cabs_c64(ar, ai) : mag_from_sq(fma(ar, ar, ai \* ai)), mag_from_sq(fma(br, br, bi \* bi))};/const v2f m = {mag_from_sq(fma(ar, ar, ai * ai)), mag_from_sq(fma(br, br, bi * bi))};/' $f ;;
       compute) python3 -c "import re,sys; s=open(sys.argv[1]).read(); s=re.sub(r'#pragma unroll\n    for \([^\n]*\) [^\n]*xb\[[^\n]*\n','',s); open(sys.argv[1],'w').write(s)" $f
-               sed -i '/out_a2\?\[.*\] = la;/d; /out_b2\?\[.*\] = lb;/d' $f
+               sed -i '/^ *aur_buf_st(l\.[xy], out, /d' $f
+               sed -i 's/if (j == 0) lg0 = l.x;/lg0 += l.x + l.y;/' $f
                sed -i 's/(f + 1 < cend) ? f + 1 : -1, hop, lane, nxt);/fstart, hop, lane, nxt);/' $f ;;
       noload)  sed -i 's/(f + 1 < cend) ? f + 1 : -1, hop, lane, nxt);/fstart, hop, lane, nxt);/' $f ;;
     esac
@@ -33,6 +38,11 @@ if [ "$1" = build ]; then
       w8l)   extra="-DAUR_STFT_WAVES_PER_WG=8 -DAUR_STFT_MID_AT=4 -DAUR_STFT_PMAG_LDS=1" ;;
       w8)    extra="-DAUR_STFT_WAVES_PER_WG=8" ;;
       mid6)  extra="-DAUR_STFT_MID_AT=6" ;;
+      mid0)  extra="-DAUR_STFT_MID_AT=0" ;;
+      mid2)  extra="-DAUR_STFT_MID_AT=2" ;;
+      nt)    extra="-DAUR_STFT_NT=1" ;;
+      w3nt)  extra="-DAUR_STFT_WAVES_PER_SIMD=3 -DAUR_STFT_WAVES_PER_WG=12 -DAUR_STFT_NT=1" ;;
+      w3m2)  extra="-DAUR_STFT_WAVES_PER_SIMD=3 -DAUR_STFT_WAVES_PER_WG=12 -DAUR_STFT_MID_AT=2" ;;
     esac
     make -s -C $d/aurora_amd/csrc OUT=../../lib_$v.so BUILD=build EXTRA="$extra" > /dev/null
     mv $d/lib_$v.so $OUT/ 2>/dev/null || mv $d/aurora_amd/lib_$v.so $OUT/ 2>/dev/null || true

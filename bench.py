@@ -70,7 +70,7 @@ def parse_args():
     ap.add_argument("--yuv-leg", type=int, default=1, help="also time one export step in the opt-in yuv420p wire format")
     ap.add_argument("--events", type=int, default=1,
                     help="0: record no HIP events around the device leg's kernels (counter passes: tools/pmc_passes.sh)")
-    ap.add_argument("--pipe-frames", type=int, default=960,
+    ap.add_argument("--pipe-frames", type=int, default=1920,
                     help="frames of the pipe leg: the same export through the product's pipe sink into a child process "
                          "that reads stdin as FFmpeg does (0 = skip)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"),

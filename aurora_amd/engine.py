@@ -433,7 +433,9 @@ class HipExportEngine:
 
     # ------------------------------------------------------------------ analysis
     def analyze(self, track: Track, frame_begin: int = 0, n_frames: int | None = None, want_samples=False,
-                want_bandmax=False, want_logspec=True) -> Analysis:
+                want_bandmax=False, want_logspec=True, reuse: "Analysis | None" = None) -> Analysis:
+        """``reuse``: an Analysis of the same shape whose tensors are overwritten instead of allocating new ones (callers
+        that analyse the same range again and again; nothing of the old contents survives)."""
         torch = self.torch
         if n_frames is None:
             n_frames = track.total_frames - frame_begin
@@ -441,11 +443,16 @@ class HipExportEngine:
             raise ValueError(f"frame range [{frame_begin}, {frame_begin + n_frames}) outside track "
                              f"of {track.total_frames} frames")
         F = int(n_frames)
-        logspec = self.empty((F, NBINS), torch.float32) if want_logspec else None
-        flux_sum = self.empty((F,), torch.float32)
-        meanabs = self.empty((F,), torch.float32)
-        samples = self.empty((F, BLOCK), torch.float32) if want_samples else None
-        bandmax = self.empty((F, 2), torch.float32) if want_bandmax else None
+        if (reuse is not None and reuse.n_frames == F and (reuse.logspec is not None) == bool(want_logspec)
+                and (reuse.samples is not None) == bool(want_samples) and (reuse.bandmax is not None) == bool(want_bandmax)):
+            logspec, flux_sum, meanabs, samples, bandmax = (reuse.logspec, reuse.flux_sum, reuse.meanabs, reuse.samples,
+                                                            reuse.bandmax)
+        else:
+            logspec = self.empty((F, NBINS), torch.float32) if want_logspec else None
+            flux_sum = self.empty((F,), torch.float32)
+            meanabs = self.empty((F,), torch.float32)
+            samples = self.empty((F, BLOCK), torch.float32) if want_samples else None
+            bandmax = self.empty((F, 2), torch.float32) if want_bandmax else None
         _lib.check(self.lib.aur_stft_frames(
             self.ctx.handle, _ptr(track.audio), max(2, track.n_samples), track.channels, _ptr(track.pos),
             int(frame_begin), F, track.hop, _ptr(logspec), _ptr(flux_sum), _ptr(meanabs), _ptr(samples),

@@ -18,6 +18,7 @@ if [ "$1" = build ]; then
       noexch)  python3 -c "import re,sys; s=open(sys.argv[1]).read(); s=re.sub(r'#pragma unroll\n    for \([^\n]*\) [^\n]*xb\[[^\n]*\n','',s); open(sys.argv[1],'w').write(s)" $f ;;
       nostore) sed -i '/^ *aur_buf_st(l\.[xy], out, /d; s/if (EMIT \&\& STORE_LOG) aur_buf_st(log1p_pos(mm), out, 4 \* 512);/if (EMIT \&\& STORE_LOG \&\& mm < 0.0f) aur_buf_st(mm, out, 2048);/' $f
                sed -i 's/if (j == 0) lg0 = l.x;/lg0 += l.x + l.y;/' $f ;;
+      samerow) sed -i 's/(void\*)(logspec + (row ? fo \* AUR_NBINS : 0)), 0, row ? AUR_NBINS \* 4 : 0, kRsrcWord3);/(void*)(logspec + (row ? (fo \& 1023) * AUR_NBINS : 0)), 0, row ? AUR_NBINS * 4 : 0, kRsrcWord3);/' $f ;;
       nomean)  sed -i 's/const float ma = block_meanabs(cur, lane, xf);/const float ma = cur[0].x;/' $f ;;
       notw)    sed -i 's/v\[i\] = cmul(v\[i\], T.tw1\[64 \* (k1 - 1)\]);/v[i] = cmul(v[i], T.wuh);/; s/v\[i\] = cmul(v\[i\], T.tw2\[hi2 \* kTw2Stride + q\]);/v[i] = cmul(v[i], T.wus);/' $f ;;
       nolog)   sed -i 's/const v2f l = j < 2 ? v2f{log1p_cr(m.x, T.lg), log1p_pos(m.y)} : log1p_pos2(m);/const v2f l = m;/' $f ;;

@@ -51,6 +51,9 @@ namespace {
 #ifndef AUR_STFT_WAVES_PER_WG
 #define AUR_STFT_WAVES_PER_WG 4
 #endif
+#ifndef AUR_STFT_WIDE_STORES
+#define AUR_STFT_WIDE_STORES 0         // 1: spectrum rows leave through an LDS stage as dwordx4 stores -- measured SLOWER (below)
+#endif
 #ifndef AUR_STFT_MID_AT
 #define AUR_STFT_MID_AT 2              // unpack slot before which the next block's loads are issued: half of v[] is dead there,
                                        // so the 32 load registers cost no extra pressure (0: before the unpack)
@@ -510,12 +513,18 @@ __device__ __forceinline__ v2f log1p_pos2(v2f x) {
 // W32^5 need a full product; T.wus equals T.wuh except in lane 0, where it carries the shift by 128 bins.
 // Returns this lane's flux partial.  When EMIT: lg0 / lg1 receive log1p|X| of bins lane and lane + 64 (band maxima),
 // and when STORE_LOG too, log1p|X| is stored to `out` (float32[1025]) as soon as it is known.
-// `out` is the frame's float32[1025] spectrum as a buffer resource (base = the frame's row, num_records = 4100 bytes): the
-// stores are buffer_store_dword with one lane-dependent offset register per direction and the bin steps as immediate
-// offsets -- no 64-bit address arithmetic per store.
+// `out` is the frame's float32[1025] spectrum as a buffer resource (base = the frame's row, num_records = 4100 bytes).
+// A lane's 17 values are 17 different 256-byte pieces of the row, and 17 buffer_store_dword per frame are what a wave pays
+// for in ISSUE, not in bandwidth (round 3: without the stores the kernel ran 15 % faster, with all stores aimed at 1 024
+// cache-resident rows it did not: profiles/r03_stft_lesions.txt).  So the row is first put together in the wave's
+// exchange buffer `stage` (free between the last exchange and the next frame: 17 ds_write_b32, lane-linear both ways)
+// and leaves as four buffer_store_dwordx4 plus one dword -- build knob AUR_STFT_WIDE_STORES=1.  Measured 0.82 ms against
+// 0.78 ms for the direct stores (profiles/r03_stft_lesions.txt): the two extra wave-wide LDS round trips per frame cost
+// more than the twelve store instructions they save, so the direct stores stay the default.
 template <bool EMIT, bool STORE_LOG, typename PM, typename MID>
 __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, PM& pm,
-                                            const __amdgpu_buffer_rsrc_t out, float& lg0, float& lg1, MID&& mid_hook) {
+                                            const __amdgpu_buffer_rsrc_t out, float* stage, float& lg0, float& lg1,
+                                            MID&& mid_hook) {
     constexpr double H = 0.70710678118654752440;
     const bool l0 = lane == 0;
     const cd wuh = opaque(T.wuh);
@@ -559,12 +568,15 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
             if (j == 0) lg0 = l.x;
             if (j == 1) lg1 = l.x;
             if (STORE_LOG) {
-                if (p == 2 || p == 3) {
-                    aur_buf_st(l.x, out, off_a2 + 256 * j);                 // bin off2 + 64 j
-                    aur_buf_st(l.y, out, off_b2 + 4 * (768 - 64 * j));      // bin 1024 - off2 - 64 j
+                // byte offsets inside the row (= inside the staged copy of it)
+                const int oa = (p == 2 || p == 3) ? off_a2 + 256 * j : off_a + 256 * j;                    // bin kA
+                const int ob = (p == 2 || p == 3) ? off_b2 + 4 * (768 - 64 * j) : off_b + (3840 - 256 * j);   // bin 1024 - kA
+                if (AUR_STFT_WIDE_STORES) {
+                    stage[oa >> 2] = l.x;
+                    stage[ob >> 2] = l.y;
                 } else {
-                    aur_buf_st(l.x, out, off_a + 256 * j);                  // bin lane + 64 j
-                    aur_buf_st(l.y, out, off_b + (3840 - 256 * j));         // bin 1024 - lane - 64 j
+                    aur_buf_st(l.x, out, oa);
+                    aur_buf_st(l.y, out, ob);
                 }
             }
         }
@@ -575,8 +587,21 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
         const float mm = mag_from_sq(fma(z8.x, z8.x, z8.y * z8.y));
         if (l0) {
             fl += fmaxf(0.0f, mm - pm.swap_mid(mm));
-            if (EMIT && STORE_LOG) aur_buf_st(log1p_pos(mm), out, 4 * 512);
+            if (EMIT && STORE_LOG) {
+                if (AUR_STFT_WIDE_STORES) stage[512] = log1p_pos(mm);
+                else aur_buf_st(log1p_pos(mm), out, 4 * 512);
+            }
         }
+    }
+    if (EMIT && STORE_LOG && AUR_STFT_WIDE_STORES) {
+        wave_sync();                                           // the row is complete in LDS
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(stage + 4 * lane + 256 * i);
+            __builtin_amdgcn_raw_buffer_store_b128(q, out, 16 * lane + 1024 * i, 0, AUR_STFT_NT ? 2 : 0);
+        }
+        if (l0) aur_buf_st(stage[1024], out, 4096);
+        wave_sync();                                           // nothing of the next frame touches the buffer before these reads
     }
     return fl;
 }
@@ -677,7 +702,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(logspec + (row ? fo * AUR_NBINS : 0)), 0, row ? AUR_NBINS * 4 : 0, kRsrcWord3);
         float fl = unpack_mag<STORE && (LOG || BM), STORE && LOG>(
-            v, lane, T, pmag, ors, lg0, lg1,
+            v, lane, T, pmag, ors, xf, lg0, lg1,
             [&]() { issue_block<C, ZT>(audio, n_samp, pos, (f + 1 < cend) ? f + 1 : -1, hop, lane, nxt); });
         if (STORE) {
             fl = wave_sum(fl);
@@ -728,7 +753,7 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
     fft_packed(prv, cur, lane, T, xb, v);
     float lg0, lg1;
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)logspec, 0, AUR_NBINS * 4, kRsrcWord3);
-    float fl = unpack_mag<true, true>(v, lane, T, pmag, ors, lg0, lg1, []() {});
+    float fl = unpack_mag<true, true>(v, lane, T, pmag, ors, reinterpret_cast<float*>(xb), lg0, lg1, []() {});
     mags_store(pmag, prev_mag, lane);
     fl = wave_sum(fl);
     if (lane == 0) flux_sum[0] = fl;

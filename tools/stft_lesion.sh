@@ -40,6 +40,10 @@ if [ "$1" = build ]; then
       w8)    extra="-DAUR_STFT_WAVES_PER_WG=8" ;;
       mid6)  extra="-DAUR_STFT_MID_AT=6" ;;
       mid0)  extra="-DAUR_STFT_MID_AT=0" ;;
+      narrow) extra="-DAUR_STFT_WIDE_STORES=0" ;;
+      widew3) extra="-DAUR_STFT_WAVES_PER_SIMD=3 -DAUR_STFT_WAVES_PER_WG=12" ;;
+      widem4) extra="-DAUR_STFT_MID_AT=4" ;;
+      widem0) extra="-DAUR_STFT_MID_AT=0" ;;
       mid2)  extra="-DAUR_STFT_MID_AT=2" ;;
       nt)    extra="-DAUR_STFT_NT=1" ;;
       w3nt)  extra="-DAUR_STFT_WAVES_PER_SIMD=3 -DAUR_STFT_WAVES_PER_WG=12 -DAUR_STFT_NT=1" ;;

@@ -627,6 +627,7 @@ class Exporter:
         self.view_state = view_state or {}
         self.gpu_rendering = bool(gpu_rendering)
         self.gpu_device = gpu_device or ("auto" if self.gpu_rendering else "")
+        self.last_stats = None            # filled by every export (see _pump)
 
     def make_renderer(self):
         return HipOffscreenRenderer(self.width, self.height, self.mode, self.color, self.sensitivity, self.fps,
@@ -656,6 +657,26 @@ class Exporter:
         return self._pump(renderer, sink, progress_cb)
 
     def _pump(self, renderer, sink, progress_cb):
+        """Frames of ``renderer`` into ``sink`` in order; fills ``self.last_stats`` (frames, seconds, frames/s, bytes on
+        the wire and, for a pipe sink, how they went in) -- the per-export figures a deployment logs
+        (``view_state["hip_stats_path"]`` makes the worker write them as JSON)."""
+        import time
+        t0 = time.perf_counter()
+        n = self._pump_frames(renderer, sink, progress_cb)
+        dt = time.perf_counter() - t0
+        per_frame = int(getattr(getattr(renderer, "_pipe", None), "frame_bytes", self.width * self.height * 3))
+        st = {"frames": int(n), "seconds": round(dt, 6), "fps": round(n / dt, 2) if dt > 0 else None,
+              "wire_format": getattr(renderer, "wire_format", "rgb24"), "bytes_per_frame": per_frame,
+              "wire_gbs": round(n * per_frame / dt / 1e9, 3) if dt > 0 else None,
+              "frame_range": [int(getattr(renderer, "frame_begin", 0)), int(getattr(renderer, "frame_begin", 0)) + int(n)],
+              "device": int(self.view_state.get("hip_device", 0) or 0)}
+        if isinstance(sink, _PipeSink):
+            st["pipe"] = {"spliced_bytes": int(sink.spliced_bytes), "copied_bytes": int(sink.copied_bytes),
+                          "path": ("write" if sink.spliced_bytes == 0 else "staged vmsplice" if sink._staged else "vmsplice")}
+        self.last_stats = st
+        return n
+
+    def _pump_frames(self, renderer, sink, progress_cb):
         total_frames = int(np.ceil(renderer.duration * self.fps)) if hasattr(renderer, "duration") else 0   # :536
         step = max(1, int(self.fps / 2))                                                                   # :545
 

@@ -9,7 +9,8 @@ reference implements in ``export/worker.py:9-85`` and consumes in ``ui/main_wind
 * exit status 0 = exported, 1 = the export itself failed, 2 = could not get as far as exporting (arguments, config,
   imports).
 
-Additions: ``hip_raw_out`` (write the raw frame stream to a file instead of FFmpeg) and ``view_state["hip_gpus"] = N``
+Additions: ``hip_raw_out`` (write the raw frame stream to a file instead of FFmpeg), ``view_state["hip_stats_path"]`` (the
+export's frames / seconds / frames per second / wire GB/s as a JSON file) and ``view_state["hip_gpus"] = N``
 (N > 1: this process only supervises; ``aurora_amd.export.sharded`` starts one child per GPU -- HIP devices
 ``view_state["hip_devices"]``, default 0 .. N-1 -- and joins the segments).
 Qt is not needed by the HIP renderer, so no QApplication is created.
@@ -107,6 +108,17 @@ def exporter_kwargs(cfg: dict) -> dict:
     return kw
 
 
+def _write_stats(path, stats) -> None:
+    """view_state["hip_stats_path"]: the export's own figures (frames, seconds, frames/s, wire GB/s, how the pipe was fed)
+    as one JSON object; best effort, never the reason an export fails."""
+    if not path or stats is None:
+        return
+    try:
+        Path(path).write_text(json.dumps(stats), encoding="utf-8")
+    except OSError:
+        pass
+
+
 def _export(cfg, exporter_mod) -> None:
     def progress(pct):
         _emit({"type": "progress", "pct": int(pct)})
@@ -124,16 +136,19 @@ def _export(cfg, exporter_mod) -> None:
         sharding.bind_near_device(_lib.load(), int(vs.get("hip_device") or 0))
     ex = exporter_mod.Exporter(**exporter_kwargs(cfg))
     raw_out = cfg.get("hip_raw_out")
-    if not raw_out:
-        ex.render_to_file(cfg["out_path"], progress_cb=progress)
-        return
-    from aurora_amd.pipeline import FileSink
-    sink = FileSink(raw_out)
     try:
-        ex.render_to_sink(sink, progress_cb=progress)
+        if not raw_out:
+            ex.render_to_file(cfg["out_path"], progress_cb=progress)
+            return
+        from aurora_amd.pipeline import FileSink
+        sink = FileSink(raw_out)
+        try:
+            ex.render_to_sink(sink, progress_cb=progress)
+        finally:
+            sink.close()
+        progress(100)
     finally:
-        sink.close()
-    progress(100)
+        _write_stats(vs.get("hip_stats_path"), getattr(ex, "last_stats", None))
 
 
 def main(argv: list[str]) -> int:

@@ -55,7 +55,8 @@ def test_worker_launched_as_the_ui_launches_it(tmp_path, mode):
     audio, wav = _track(tmp_path, sr)
     out = tmp_path / "out.mp4"
     cfg = dict(project_root=str(tmp_path), audio_path=str(wav), out_path=str(out), width=W, height=H, fps=fps, mode=mode,
-               color=[0.2, 0.8, 1.0], sensitivity=1.0, prefer_hevc=False, view_state={}, gpu_device="")
+               color=[0.2, 0.8, 1.0], sensitivity=1.0, prefer_hevc=False,
+               view_state={"hip_stats_path": str(tmp_path / "stats.json")}, gpu_device="")
     cfg_path = tmp_path / "export_cfg.json"
     cfg_path.write_text(json.dumps(cfg))
     res = subprocess.run([sys.executable, os.path.join(DROPIN, "export", "worker.py"), str(cfg_path)], cwd=str(tmp_path),
@@ -68,6 +69,9 @@ def test_worker_launched_as_the_ui_launches_it(tmp_path, mode):
     # export/exporter.py:545-549, :561-565: int(i * 100 / total) every max(1, int(fps / 2)) frames, then 100
     assert pcts == [int(i * 100 / F) for i in range(0, F, max(1, int(fps / 2)))] + [100]
     got = np.frombuffer(out.read_bytes(), np.uint8).reshape(F, H, W, 3)
+    stats = json.loads((tmp_path / "stats.json").read_text())          # view_state["hip_stats_path"]
+    assert stats["frames"] == F and stats["bytes_per_frame"] == W * H * 3 and stats["frame_range"] == [0, F]
+    assert stats["fps"] > 0 and stats["pipe"]["spliced_bytes"] + stats["pipe"]["copied_bytes"] == F * W * H * 3
     if mode != "Spectrum - Radial":
         pen, _ = A.amp_to_color_track(ref["energy"])
         for f in (0, 1, F // 2, F - 1):

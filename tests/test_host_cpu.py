@@ -470,6 +470,9 @@ def test_run_pipe_matches_reference_loop(tmp_path):
     assert r.times == [i / 4 for i in range(9)]                        # ceil(2.1 * 4) frames at t = i / fps
     assert out.read_bytes() == b"".join(bytes([k]) * 24 for k in range(1, 10))
     assert seen == [0, 22, 44, 66, 88, 100]
+    st = ex.last_stats                                                 # the export's own figures (hip_stats_path)
+    assert st["frames"] == 9 and st["bytes_per_frame"] == 24 and st["frame_range"] == [0, 9] and st["wire_format"] == "rgb24"
+    assert st["pipe"] == {"spliced_bytes": 0, "copied_bytes": 9 * 24, "path": "write"} and st["seconds"] > 0
     # a progress callback that raises is ignored (:546-549)
     ex._run_pipe(_DuckRenderer(0.5, (2, 4, 3)), sink_cmd, progress_cb=lambda p: 1 / 0)
     fail_cmd = [sys.executable, "-c", "import sys; sys.stdin.buffer.read(); sys.stderr.write('boom'); sys.exit(3)"]

@@ -35,6 +35,7 @@ import subprocess
 import sys
 import tempfile
 import threading
+import time
 from pathlib import Path
 
 from .. import sharding
@@ -294,36 +295,71 @@ def export_sharded(cfg: dict, world: int, progress_cb=None, worker_cmd=None, dev
     return report
 
 
-def export_tracks(cfgs, world: int, progress_cb=None, worker_cmd=None, devices=None):
-    """Many tracks: GPU g exports tracks g, g + world, ... one after another (``sharding.track_assignment``)."""
+def export_tracks(cfgs, world: int, progress_cb=None, worker_cmd=None, devices=None, prestart_pct=None):
+    """Many tracks: GPU g exports tracks g, g + world, ... one after another (``sharding.track_assignment``), the next
+    track's worker started when the current one reports ``prestart_pct`` per cent (default 96, ``AUR_TRACK_PRESTART_PCT``;
+    101 = strictly one after another)."""
     world = int(world)
+    if prestart_pct is None:
+        try:
+            prestart_pct = int(os.environ.get("AUR_TRACK_PRESTART_PCT", "96"))
+        except ValueError:
+            prestart_pct = 96
     devices = list(devices) if devices else list(range(world))
     n = len(cfgs)
     finished = [0]
     failures, lock = [], threading.Lock()
 
     def gpu_lane(g, tmp):
-        for k in sharding.track_assignment(n, world, g):
-            with lock:
-                if failures:
-                    return
+        # One worker process per track (the reference's protocol: one config, one process).  A worker spends its first
+        # seconds on the CPU -- interpreter, torch, HIP start-up, decoding and uploading the track -- so the next track's
+        # worker is started while the current one renders its last few per cent: the GPU goes from one track's frames to
+        # the next one's without the start-up in between (about 4 s per 94 s track of configs[4]).
+        queue = sharding.track_assignment(n, world, g)
+        running, nxt = [], 0
+
+        def start(k):
             c = copy.deepcopy(cfgs[k])
             vs = dict(c.get("view_state") or {})
             vs.pop("hip_gpus", None)
             vs["hip_device"] = int(devices[g % len(devices)])
             c["view_state"] = vs
-            ch = _Child(c, tmp, f"track{k:04d}", worker_cmd or default_worker_cmd(), lambda: None)
+            return _Child(c, tmp, f"track{k:04d}", worker_cmd or default_worker_cmd(), lambda: None)
+
+        def abort():
+            for ch in running:
+                ch.stop()
+            for ch in running:
+                ch.wait()
+
+        while nxt < len(queue) or running:
+            with lock:
+                if failures:
+                    abort()
+                    return
+            if nxt < len(queue) and (not running or (len(running) == 1 and running[0].pct >= prestart_pct)):
+                running.append(start(queue[nxt]))
+                nxt += 1
+                continue
+            ch = running[0]
+            if ch.proc.poll() is None:
+                time.sleep(0.05)
+                continue
             msg = ch.failure(ch.wait())
+            running.pop(0)
             with lock:
                 if msg:
                     failures.append(msg)
-                    return
-                finished[0] += 1
-                if progress_cb is not None:
-                    try:
-                        progress_cb(int(finished[0] * 100 / n))
-                    except Exception:
-                        pass
+                else:
+                    finished[0] += 1
+                    if progress_cb is not None:
+                        try:
+                            progress_cb(int(finished[0] * 100 / n))
+                        except Exception:
+                            pass
+            if msg:
+                abort()
+                return
 
     with tempfile.TemporaryDirectory(prefix="aurora_tracks_") as tmp:
         lanes = [threading.Thread(target=gpu_lane, args=(g, tmp), daemon=True) for g in range(world)]

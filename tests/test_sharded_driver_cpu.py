@@ -41,8 +41,13 @@ FAKE_WORKER = textwrap.dedent('''
             fh.write(bytes([f % 251]) * fb)
             if f % 7 == 0:
                 print(json.dumps({"type": "progress", "pct": int(f * 100 / total)}), flush=True)
+    t_start = time.time()
+    if cfg.get("fake_tail_sleep"):                # the last few per cent of a real export take a while
+        print(json.dumps({"type": "progress", "pct": 97}), flush=True)
+        time.sleep(float(cfg["fake_tail_sleep"]))
     with open(out + ".meta", "w") as fh:
-        json.dump({"device": vs.get("hip_device"), "segment": bool(vs.get("hip_segment")), "pid": os.getpid()}, fh)
+        json.dump({"device": vs.get("hip_device"), "segment": bool(vs.get("hip_segment")), "pid": os.getpid(),
+                   "start": t_start, "end": time.time()}, fh)
     print(json.dumps({"type": "progress", "pct": 100}), flush=True)
     print(json.dumps({"type": "done"}), flush=True)
 ''')
@@ -207,6 +212,21 @@ def test_many_tracks_are_dealt_over_gpu_lanes(tmp_path, fake_worker):
         assert (tmp_path / f"t{k}.rgb").read_bytes() == _expected(10 + k, 4)
         assert json.load(open(str(tmp_path / f"t{k}.rgb") + ".meta"))["device"] == k % 3     # track k on GPU k mod 3
     assert seen[-1] == 100
+
+
+def test_next_tracks_worker_starts_during_the_tail_of_the_current_one(tmp_path, fake_worker):
+    """A lane starts the next track's worker once the current one reports 96 % (start-up hidden behind the tail); with
+    prestart_pct=101 the workers of a lane run strictly one after another."""
+    def run(prestart, tag):
+        cfgs = [_cfg(tmp_path, 10, 4, hip_raw_out=str(tmp_path / f"{tag}{k}.rgb"), fake_tail_sleep=0.6) for k in range(3)]
+        assert sharded.export_tracks(cfgs, 1, None, worker_cmd=fake_worker, prestart_pct=prestart) == 3
+        return [json.load(open(str(tmp_path / f"{tag}{k}.rgb") + ".meta")) for k in range(3)]
+    over = run(96, "a")
+    assert all((tmp_path / f"a{k}.rgb").read_bytes() == _expected(10, 4) for k in range(3))
+    assert over[1]["start"] < over[0]["end"]                                             # overlapped start-up
+    assert over[2]["start"] >= over[0]["end"] - 0.05                                     # never three at once
+    serial = run(101, "b")
+    assert serial[1]["start"] >= serial[0]["end"] and serial[2]["start"] >= serial[1]["end"]
 
 
 def test_cli_and_worker_dispatch(tmp_path, fake_worker, capsys, monkeypatch):

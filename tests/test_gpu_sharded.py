@@ -100,3 +100,28 @@ def test_per_shard_ffmpeg_segments_and_concat(eng, tmp_path, monkeypatch):
     assert out.returncode == 0 and lines[-1] == {"type": "done"}, (out.stdout[-2000:], out.stderr[-2000:])
     got = open(cfg["out_path"], "rb").read()
     assert got == _unsharded(eng, audio, dims, "Spectrum - Linear", 1.2)
+
+
+def test_many_tracks_on_one_lane_with_overlapped_start_up(eng, tmp_path):
+    """BASELINE configs[4] in miniature: several tracks dealt to one GPU lane, each exported by its own worker process, the
+    next worker started while the current one renders its tail (two workers share the card for a moment).  Every track's
+    stream equals its unsharded export."""
+    from scipy.io import wavfile
+    from aurora_amd import synth
+    from aurora_amd.export import sharded
+    sr, fps, W, H = 48000, 60, 320, 192
+    cfgs, audios = [], []
+    for k in range(3):
+        audio = synth.pink(sr * 2 + 100 * k, 2, seed=40 + k)
+        wav = tmp_path / f"in{k}.wav"
+        wavfile.write(str(wav), sr, audio)
+        audios.append(audio)
+        cfgs.append(dict(audio_path=str(wav), out_path=str(tmp_path / f"o{k}.mp4"), width=W, height=H, fps=fps,
+                         mode="Spectrum - Linear", color=[0.2, 0.8, 1.0], sensitivity=1.0,
+                         view_state={"hip_batch_frames": 8}, gpu_device="", hip_raw_out=str(tmp_path / f"t{k}.rgb")))
+    seen = []
+    assert sharded.export_tracks(cfgs, 1, seen.append, devices=[0], prestart_pct=50) == 3
+    assert seen == [33, 66, 100]
+    for k in range(3):
+        got = open(cfgs[k]["hip_raw_out"], "rb").read()
+        assert got == _unsharded(eng, audios[k], (sr, fps, W, H), "Spectrum - Linear", 1.0), k

@@ -422,6 +422,10 @@ class _PipeSink:
 
     def __init__(self, stdin, splice=None, staged=None):
         self._stdin = stdin
+        try:                                      # tuning knob (tools/pipe_shards.py): staging chunk in MiB
+            self.CHUNK = max(4, int(os.environ.get("AUR_PIPE_CHUNK_MB", "16"))) << 20
+        except ValueError:
+            pass
         self.spliced_bytes = 0
         self.copied_bytes = 0
         self.refused_errno = None         # errno of the vmsplice call that sent this sink to the staged path

@@ -410,20 +410,21 @@ class _PipeSink:
       bytes in pages of 4 KiB, so by the time that copy has fitted, every spliced page before it has left the pipe.
     * **staged**: the ring itself cannot be spliced -- ``hipHostMalloc`` memory is a device-file mapping (``vmsplice``
       answers EFAULT) and this pool refuses ``hipHostRegister`` of anonymous memory (``profiles/r03_hostreg_probe.txt``) --
-      so chunks of it are copied by a few threads into three page-aligned staging buffers of the sink's own and spliced
+      so chunks of it (32 MiB) are copied by a few threads into three page-aligned staging buffers of the sink's own and spliced
       from there; a staging buffer is overwritten only after a whole later chunk (at least ``capacity`` bytes) has been
       spliced behind it, which by the same first-in first-out argument means its pages have left the pipe.
 
     Either way ``write`` means what it always meant: on return the pipe refers to nothing of the caller's memory.
     Buffers under ``4 * capacity`` and hosts without ``vmsplice`` take the plain path.  ``AUR_PIPE_SPLICE=0`` turns
-    splicing off, ``AUR_PIPE_COPY_THREADS`` sets the staging copy threads (default 4)."""
+    splicing off, ``AUR_PIPE_COPY_THREADS`` sets the staging copy threads (default 3), ``AUR_PIPE_CHUNK_MB`` the staging chunk (default 32;
+    sweeps of both: ``profiles/r03_pipe_tune.txt``)."""
 
-    CHUNK = 16 << 20
+    CHUNK = 32 << 20
 
     def __init__(self, stdin, splice=None, staged=None):
         self._stdin = stdin
         try:                                      # tuning knob (tools/pipe_shards.py): staging chunk in MiB
-            self.CHUNK = max(4, int(os.environ.get("AUR_PIPE_CHUNK_MB", "16"))) << 20
+            self.CHUNK = max(4, int(os.environ.get("AUR_PIPE_CHUNK_MB", "32"))) << 20
         except ValueError:
             pass
         self.spliced_bytes = 0
@@ -479,7 +480,7 @@ class _PipeSink:
             size = self.CHUNK + self._cap
             maps = [mmap.mmap(-1, size) for _ in range(3)]                       # page-aligned, the sink's own
             bufs = [np.frombuffer(m, dtype=np.uint8) for m in maps]
-            threads = max(1, int(os.environ.get("AUR_PIPE_COPY_THREADS", "4") or 4))
+            threads = max(1, int(os.environ.get("AUR_PIPE_COPY_THREADS", "3") or 3))    # profiles/r03_pipe_tune.txt
             self._stage = (bufs, ThreadPoolExecutor(threads, thread_name_prefix="aurora-pipe-stage"), threads, maps)
         return self._stage
 

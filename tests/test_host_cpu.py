@@ -752,8 +752,9 @@ def _drain_child(extra=()):
                             stdin=subprocess.PIPE, stdout=subprocess.PIPE, bufsize=10 ** 7)
 
 
-_PIPE_SIZES = (24_000_011, 5, 4 * (1 << 20), 4 * (1 << 20) - 1, 1_000_003, 0, 16 << 20, (16 << 20) + 1, (17 << 20) - 1,
-               17 << 20, (32 << 20) + 100, 17_123_457, 40_000_001)
+_CH = 32 << 20        # the sink's staging chunk (exporter._PipeSink.CHUNK): sizes around one, two and three chunks
+_PIPE_SIZES = (24_000_011, 5, 4 * (1 << 20), 4 * (1 << 20) - 1, 1_000_003, 0, _CH, _CH + 1, _CH + (1 << 20) - 1,
+               _CH + (1 << 20), 2 * _CH + 100, 17_123_457, 2 * _CH + (1 << 20) + 7, 70_000_003)
 
 
 @pytest.mark.parametrize("path", ["plain", "direct", "staged"])
@@ -764,6 +765,7 @@ def test_pipe_sink_stream_is_the_written_bytes_even_when_buffers_are_reused(path
     memory is never in the pipe and a staging buffer is reused only after a whole later chunk went in behind it."""
     import hashlib
     from aurora_amd.export.exporter import _PipeSink, _grow_pipe
+    assert _PipeSink.CHUNK == _CH
     child = _drain_child(("--chunk", "4096"))
     cap = _grow_pipe(child.stdin)
     sink = _PipeSink(child.stdin, splice=path != "plain", staged=path == "staged")

@@ -415,6 +415,10 @@ class _PipeSink:
       spliced behind it, which by the same first-in first-out argument means its pages have left the pipe.
 
     Either way ``write`` means what it always meant: on return the pipe refers to nothing of the caller's memory.
+    One assumption about the far end: it takes bytes out of the pipe by READING them (FFmpeg does: ``read`` into its own
+    packet buffers).  A consumer that moves the pipe's pages onward without copying (``splice`` / ``tee`` into a socket or
+    another pipe) would keep references to staging pages after they have "left the pipe"; for such a consumer set
+    ``AUR_PIPE_SPLICE=0``.
     Buffers under ``4 * capacity`` and hosts without ``vmsplice`` take the plain path.  ``AUR_PIPE_SPLICE=0`` turns
     splicing off, ``AUR_PIPE_COPY_THREADS`` sets the staging copy threads (default 3), ``AUR_PIPE_CHUNK_MB`` the staging chunk (default 32;
     sweeps of both: ``profiles/r03_pipe_tune.txt``)."""

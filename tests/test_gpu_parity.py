@@ -1660,3 +1660,94 @@ def test_zero_padding_is_the_buffer_range_check(eng, hop, channels):
         want[:nv] = 1.0
         assert np.array_equal(got[f], want), (hop, channels, f, int(p), nv, int(got[f].sum()))
     assert np.array_equal(mean.cpu().numpy(), np.asarray([min(hop, 1024, n_decl - p) / 1024 for p in pos_host], np.float32))
+
+
+def _special_signal(kind, n):
+    t = np.arange(n, dtype=np.float64)
+    if kind == "silence":
+        x = np.zeros(n)
+    elif kind == "dc":
+        x = np.ones(n)
+    elif kind == "nyquist":
+        x = np.where(np.arange(n) % 2 == 0, 1.0, -1.0)
+    elif kind == "impulse":
+        x = np.zeros(n)
+        x[n // 3] = 1.0
+    elif kind == "square_full_scale":
+        x = np.sign(np.sin(2 * np.pi * 441.0 * t / 48000.0))
+    elif kind == "tiny":
+        x = 1e-30 * np.sin(2 * np.pi * 1000.0 * t / 48000.0)
+    elif kind == "denormal":
+        x = 3e-39 * np.sin(2 * np.pi * 1000.0 * t / 48000.0)          # float32 subnormals after the window product
+    elif kind == "clipped_over_unity":
+        x = 4.0 * np.sin(2 * np.pi * 3000.0 * t / 48000.0)            # a float WAV may exceed [-1, 1]
+    else:
+        raise ValueError(kind)
+    x = x.astype(np.float32)
+    return np.stack([x, x[::-1].copy()], axis=1) if kind in ("impulse", "square_full_scale") else np.stack([x, x], axis=1)
+
+
+@pytest.mark.parametrize("kind", ["silence", "dc", "nyquist", "impulse", "square_full_scale", "tiny", "denormal",
+                                  "clipped_over_unity"])
+def test_special_signals_follow_the_oracle(eng, kind):
+    """Inputs at the edges of the arithmetic: digital silence (every maximum is 0: the reference divides by 1,
+    rt_widget.py:936-937), DC, the Nyquist tone, one impulse, a full-scale square wave, amplitudes of 1e-30 and in the
+    float32 subnormal range, samples beyond [-1, 1] (energy clips at 1, rt_widget.py:824).  Samples, energy, pen and phase
+    bit-exact; spectrum within the north star's tolerance; frames of all three span modes against the oracle rasteriser fed
+    the GPU's own spectrum (bit-exact) and the oracle's own (at most a bar top of difference)."""
+    sr, fps, W, H = 48000, 60, 640, 360
+    audio = _special_signal(kind, sr // 2 + 313)
+    ref = A.analyze_track(audio, sr, fps)
+    pen_ref, _ = A.amp_to_color_track(ref["energy"])
+    track = eng.upload_track(audio, sr, fps)
+    an = eng.analyze(track, want_samples=True)
+    sc = eng.scan(an)
+    assert np.array_equal(_np(an.samples), ref["samples"])
+    assert np.array_equal(_np(sc.energy), ref["energy"])
+    assert np.array_equal(_np(sc.pen_rgb)[:, :3], pen_ref)
+    assert np.array_equal(_np(sc.phase), A.phase_track(ref["energy"]))
+    got = _np(an.logspec)
+    assert np.all(np.isfinite(got))
+    assert np.allclose(got, ref["logspec"], rtol=RTOL, atol=ATOL), float(np.max(np.abs(got - ref["logspec"])))
+    assert np.allclose(_np(sc.flux_smooth), ref["flux_smooth"], rtol=1e-4, atol=1e-7)
+    for mode in ("Spectrum - Linear", "Waveform - Linear", "Particles"):
+        frames = _np(eng.render(mode, an, sc, W, H))
+        for f in (0, 1, an.n_frames // 2, an.n_frames - 1):
+            own = R.render_frame(mode, ref["samples"][f], got[f], float(ref["energy"][f]), pen_ref[f], W, H)
+            assert np.array_equal(frames[f], own), (kind, mode, f, int(np.sum(frames[f] != own)))
+            theirs = R.render_frame(mode, ref["samples"][f], ref["logspec"][f], float(ref["energy"][f]), pen_ref[f], W, H)
+            assert int(np.sum(np.any(frames[f] != theirs, axis=2))) <= 4, (kind, mode, f)
+
+
+@pytest.mark.parametrize("kind", ["silence", "dc", "impulse", "clipped_over_unity"])
+def test_special_signals_closed_path_modes(eng, kind):
+    """The same edge inputs through "Spectrum - Radial" (normalisation by a zero maximum, rt_widget.py:944-945; ring EMA;
+    antialiased disc) and "Waveform - Circular": vertices against the oracle's chain, frames against the oracle rasteriser
+    on the GPU's own vertices (bit-exact)."""
+    from aurora_amd.pipeline import FramePipeline
+    from oracle import radial_ref as RR
+    sr, fps, W, H = 48000, 60, 640, 360
+    audio = _special_signal(kind, 800 * 12 + 5)
+    ref = A.analyze_track(audio, sr, fps)
+    pen_ref, _ = A.amp_to_color_track(ref["energy"])
+    track = eng.upload_track(audio, sr, fps)
+    pipe = FramePipeline(eng, track, "Spectrum - Radial", W, H)
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    verts, env = eng.radial_vertices(pipe._radial_prep, an, sc, W, H, 0, an.n_frames)
+    verts, env = _np(verts), _np(env)
+    assert np.all(np.isfinite(verts)) and np.all(np.isfinite(env))
+    tr = RR.RadialTrack()
+    for f in range(an.n_frames):
+        want_path = tr.path(ref["logspec"][f], float(ref["energy"][f]), W, H)
+        assert np.allclose(verts[f], want_path, rtol=0, atol=2e-3), (kind, f)
+        if f in (0, 1, an.n_frames - 1):
+            assert np.array_equal(frames[f], R.render_radial_frame(verts[f], env[f], pen_ref[f], W, H)), (kind, f)
+    pipe = FramePipeline(eng, track, "Waveform - Circular", W, H)
+    an, sc = pipe.analyse()
+    frames = _np(pipe.render_device())
+    cverts = _np(eng.wave_circular_vertices(an, sc, W, H, 0, an.n_frames))
+    for f in (0, 1, an.n_frames - 1):
+        want_path = RR.wave_circular_path(ref["samples"][f], float(ref["energy"][f]), W, H)
+        assert np.array_equal(cverts[f], want_path), (kind, f)
+        assert np.array_equal(frames[f], R.render_wave_circular_frame(want_path, pen_ref[f], W, H)), (kind, f)

@@ -125,3 +125,32 @@ def test_many_tracks_on_one_lane_with_overlapped_start_up(eng, tmp_path):
     for k in range(3):
         got = open(cfgs[k]["hip_raw_out"], "rb").read()
         assert got == _unsharded(eng, audios[k], (sr, fps, W, H), "Spectrum - Linear", 1.0), k
+
+
+def test_more_shards_than_frames_with_real_workers(eng, tmp_path):
+    """A 4-frame track over 6 time shards (more GPUs than frames): the real workers of the empty shards start no FFmpeg and
+    leave no segment, the concat join takes the four that exist, and the result is the unsharded stream."""
+    from scipy.io import wavfile
+    from aurora_amd import synth
+    from aurora_amd.export import sharded
+    ff = tmp_path / "ffmpeg"
+    ff.write_text(FAKE_FFMPEG)
+    ff.chmod(ff.stat().st_mode | stat.S_IXUSR)
+    sr, fps, W, H = 48000, 60, 320, 192
+    audio = synth.pink(800 * 4 - 10, 2, seed=3)
+    wav = tmp_path / "short.wav"
+    wavfile.write(str(wav), sr, audio)
+    cfg = dict(audio_path=str(wav), out_path=str(tmp_path / "short.mp4"), width=W, height=H, fps=fps,
+               mode="Spectrum - Linear", color=[0.2, 0.8, 1.0], sensitivity=1.0, view_state={}, gpu_device="")
+    old = os.environ.get("AURORA_FFMPEG")
+    os.environ["AURORA_FFMPEG"] = str(ff)
+    try:
+        sharded.export_sharded(cfg, 6, None, devices=[0])
+    finally:
+        if old is None:
+            os.environ.pop("AURORA_FFMPEG", None)
+        else:
+            os.environ["AURORA_FFMPEG"] = old
+    want = _unsharded(eng, audio, (sr, fps, W, H), "Spectrum - Linear", 1.0)
+    assert len(want) == 4 * W * H * 3 and open(cfg["out_path"], "rb").read() == want
+    assert not list(tmp_path.glob("short.seg*.mp4"))

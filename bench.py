@@ -212,6 +212,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    t_start = time.perf_counter()
+
+    def note(msg):
+        # progress on stderr (stdout carries the one JSON line): a long run must not look hung to whoever watches it
+        if rank == 0:
+            print(f"[bench {time.perf_counter() - t_start:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
     # BASELINE.json configs[3]: "particle mode + audio-reactive image feather".  The reference draws the centre disc and
     # its feather only in "Spectrum - Radial" (rt_widget.py:841-849), so this is the union of the work:
     # particle frames with the audio-reactive disc envelope and the six feather rings composited on top (device leg only).
@@ -251,16 +258,18 @@ def main():
     roof, wire_bytes, dt = None, frame_bytes, 1.0
     if args.steps > 0:
         pipe = make_pipe(args.wire)                    # device slots + pinned ring allocated here, before the clock
-        for _ in range(args.warmup):
+        for k in range(args.warmup):
             export_step(pipe)
+            note(f"export warm-up step {k + 1}/{args.warmup}")
         ev_fill, ev_stft_small = [], []
         if not planes_mode:
             pipe.fill_events = ev_fill
         pipe.stft_events = ev_stft_small
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for k in range(args.steps):
             export_step(pipe)
+            note(f"export step {k + 1}/{args.steps}")
         barrier()
         dt = time.perf_counter() - t0
         dt = sharding.max_over_ranks(dt, device if backend == "nccl" else None)
@@ -283,6 +292,7 @@ def main():
         yuv_bytes = p2.frame_bytes
         p2.close()
         del p2
+        note("yuv420p leg done")
     # ------------------------------------------------------------------ pipe leg: the boundary the reference ends at
     # export/exporter.py:532-542 ends at proc.stdin.write: the same export through the product's own pipe sink
     # (aurora_amd.export.exporter._PipeSink behind _grow_pipe) into a fresh child that reads stdin and discards
@@ -313,10 +323,14 @@ def main():
             return {"fps": round(PF / t, 1), "gbs": round(PF * p.frame_bytes / t / 1e9, 2), "bytes_per_frame": p.frame_bytes,
                     "pipe_bytes": cap, "path": how, "spliced_frac": round(sink.spliced_bytes / max(1, rep["bytes"]), 4)}
 
-        pipe_leg = {"frames": PF, "reader": "tools/pipe_drain.py: read() of 4 MiB into its own buffer, discards",
-                    "rgb24": piped("rgb24", None), "rgb24_plain_write": piped("rgb24", False)}
+        pipe_leg = {"frames": PF, "reader": "tools/pipe_drain.py: read() of 4 MiB into its own buffer, discards"}
+        pipe_leg["rgb24"] = piped("rgb24", None)
+        note("pipe leg: rgb24 done")
+        pipe_leg["rgb24_plain_write"] = piped("rgb24", False)
+        note("pipe leg: rgb24 with plain write done")
         if W % 4 == 0 and H % 2 == 0:
             pipe_leg["yuv420p"] = piped("yuv420p", None)
+            note("pipe leg: yuv420p done")
     del track, audio
     torch.cuda.empty_cache()
 
@@ -385,6 +399,7 @@ def main():
 
         for _ in range(args.device_warmup):
             step()
+        note("device leg warm-up done")
         ev_f, ev_s = [], []
         barrier()
         t1 = time.perf_counter()
@@ -392,6 +407,7 @@ def main():
             step(ev_f, ev_s) if args.events else step()
         barrier()
         ddt = sharding.max_over_ranks(time.perf_counter() - t1, device if backend == "nccl" else None)
+        note("device leg done")
         roof_dev = kernel_stats(ev_f, frame_bytes)
         roof_stft = kernel_stats(ev_s, stft_bytes)
         if roof_stft is not None:                      # a read-and-compute kernel: the store ceiling says nothing about it
@@ -459,6 +475,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         cpu = cpu_baseline(args)
+        note("CPU baseline done")
 
     if rank == 0:
         out = {

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Which page-locked allocations can be spliced into a pipe?  vmsplice of aur_host_alloc memory of several sizes (and of
-plain anonymous memory registered with the runtime afterwards, if the entry point exists), errno on refusal, GB/s."""
+"""Which memory can the product's pipe sink splice into a pipe?  aur_host_alloc (hipHostMalloc) memory and ordinary
+pageable memory of several sizes: GB/s into a reading child, how much of it was spliced, errno on refusal, and the
+device-to-host copy rate into the pinned kind.  (Anonymous memory registered with hipHostRegister: the pool refuses the
+registration, tools/probes/hostreg_probe.hip.)"""
 import ctypes as C
 import json
 import os
@@ -23,9 +25,6 @@ def run(nbytes, reps, kind):
     p = C.c_void_p()
     if kind == "pinned":
         _lib.check(lib.aur_host_alloc(C.byref(p), nbytes), "aur_host_alloc")
-        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
-    elif kind == "pages":
-        _lib.check(lib.aur_host_alloc_pages(C.byref(p), nbytes), "aur_host_alloc_pages")
         arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
     else:
         arr = np.empty(nbytes, np.uint8)
@@ -57,11 +56,10 @@ def run(nbytes, reps, kind):
            "spliced_frac": round(sink.spliced_bytes / rep["bytes"], 4), "refused_errno": getattr(sink, "refused_errno", None), "d2h_GBps": d2h}
     if kind == "pinned":
         lib.aur_host_free(p)
-    elif kind == "pages":
-        lib.aur_host_free_pages(p, nbytes)
+
     print(json.dumps(out), flush=True)
 
 
-for kind in ("pinned", "pages", "pageable"):
+for kind in ("pinned", "pageable"):
     for nbytes, reps in ((11 << 20, 200), (256 << 20, 16), (1592524800, 3)):
         run(nbytes, reps, kind)

@@ -84,6 +84,8 @@ def shard_configs(cfg: dict, world: int, devices=None) -> list:
         vs.pop("hip_devices", None)
         vs["hip_shard"] = [r, world]
         vs["hip_device"] = int(devices[r % len(devices)])
+        if vs.get("hip_stats_path"):                       # every shard reports its own figures
+            vs["hip_stats_path"] = segment_path(str(vs["hip_stats_path"]), r)
         if c.get("hip_raw_out"):
             c["hip_raw_out"] = segment_path(str(c["hip_raw_out"]), r)
         else:

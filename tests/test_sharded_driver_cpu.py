@@ -96,6 +96,8 @@ def test_shard_configs_are_rank_ordered_ranges(tmp_path):
     enc = sharded.shard_configs(_cfg(tmp_path), 2)
     assert enc[1]["out_path"].endswith("out.seg001.mp4") and enc[1]["view_state"]["hip_segment"] is True
     assert cfg["view_state"] == {"hip_gpus": 3}                         # the caller's config is not modified
+    st = sharded.shard_configs(dict(_cfg(tmp_path), view_state={"hip_stats_path": "/tmp/s.json"}), 2)
+    assert [c["view_state"]["hip_stats_path"] for c in st] == ["/tmp/s.seg000.json", "/tmp/s.seg001.json"]
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])

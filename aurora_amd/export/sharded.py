@@ -111,6 +111,7 @@ class _Child:
         self.pct = 0
         self.error = None
         self.done = False
+        self.last_sign = time.monotonic()          # when the worker last said anything (stall detection)
         self._on_progress = on_progress
         # its own session = its own process group: stopping a worker also stops the FFmpeg it started
         self.proc = subprocess.Popen(list(worker_cmd) + [self.cfg_path], stdout=subprocess.PIPE,
@@ -124,6 +125,7 @@ class _Child:
 
     def _read_stdout(self):
         for raw in self.proc.stdout:
+            self.last_sign = time.monotonic()
             try:
                 msg = json.loads(raw.decode("utf-8", "ignore"))
             except ValueError:
@@ -171,9 +173,27 @@ class _Child:
             pass
 
 
-def _run_children(children):
-    """Waits for every child; the first failure stops the others.  Returns the failure messages."""
+def _run_children(children, stall_timeout_s=None):
+    """Waits for every child; the first failure stops the others.  ``stall_timeout_s``: a worker that has been silent for
+    that long (no progress line: a hung GPU, a wedged FFmpeg) counts as failed and is stopped with the rest -- the
+    reference has no such guard (a stuck export hangs its UI job for good); off unless asked for.
+    Returns the failure messages."""
     failures, lock = [], threading.Lock()
+    finished = threading.Event()
+
+    def watchdog():
+        while not finished.wait(0.2):
+            now = time.monotonic()
+            for ch in children:
+                if ch.proc.poll() is None and now - ch.last_sign > stall_timeout_s:
+                    with lock:
+                        failures.append(f"{ch.tag}: no sign of life for {stall_timeout_s:.0f} s, stopped")
+                    for other in children:
+                        other.stop()
+                    return
+
+    if stall_timeout_s:
+        threading.Thread(target=watchdog, daemon=True).start()
 
     def watch(ch):
         msg = ch.failure(ch.wait())
@@ -189,6 +209,7 @@ def _run_children(children):
         t.start()
     for t in threads:
         t.join()
+    finished.set()
     return failures
 
 
@@ -239,9 +260,14 @@ def join_encoded_segments(paths, audio_path: str, out_path: str, keep: bool = Fa
             os.remove(p)
 
 
-def export_sharded(cfg: dict, world: int, progress_cb=None, worker_cmd=None, devices=None, keep_segments=False):
-    """One track over ``world`` GPUs.  Raises RuntimeError with the children's messages on failure."""
+def export_sharded(cfg: dict, world: int, progress_cb=None, worker_cmd=None, devices=None, keep_segments=False,
+                   stall_timeout_s=None):
+    """One track over ``world`` GPUs.  Raises RuntimeError with the children's messages on failure.
+    ``stall_timeout_s`` (or ``view_state["hip_stall_timeout_s"]``): see ``_run_children``."""
     world = int(world)
+    if stall_timeout_s is None:
+        stall_timeout_s = (cfg.get("view_state") or {}).get("hip_stall_timeout_s")
+    stall_timeout_s = float(stall_timeout_s) if stall_timeout_s else None
     children_cfg = shard_configs(cfg, world, devices)
     last = [-1]
     lock = threading.Lock()
@@ -267,7 +293,7 @@ def export_sharded(cfg: dict, world: int, progress_cb=None, worker_cmd=None, dev
     with tempfile.TemporaryDirectory(prefix="aurora_shards_") as tmp:
         for r, c in enumerate(children_cfg):                          # all children start before anything else happens
             children.append(_Child(c, tmp, f"shard{r:03d}", worker_cmd or default_worker_cmd(), on_progress))
-        failures = _run_children(children)           # returns when every worker has been waited for
+        failures = _run_children(children, stall_timeout_s)   # returns when every worker has been waited for
     if failures:
         for ch in children:
             ch.reap_group()

@@ -192,6 +192,19 @@ def test_stopping_a_worker_stops_what_it_started(tmp_path, fake_worker):
         raise AssertionError("the stopped worker's child is still running")
 
 
+def test_a_silent_worker_is_stopped_after_the_stall_timeout(tmp_path, fake_worker):
+    """Opt-in stall detection: a worker that says nothing for `hip_stall_timeout_s` seconds is taken for hung; the export
+    fails with a message that names it instead of waiting for good."""
+    import time
+    cfg = _cfg(tmp_path, hip_raw_out=str(tmp_path / "frames.rgb"), fake_hang_rank=1)
+    cfg["view_state"] = {"hip_stall_timeout_s": 1.0}
+    t0 = time.time()
+    with pytest.raises(RuntimeError) as ei:
+        sharded.export_sharded(cfg, 2, None, worker_cmd=fake_worker, devices=[0])
+    assert "shard001: no sign of life for 1 s" in str(ei.value) and time.time() - t0 < 30
+    assert not list(tmp_path.glob("frames.seg*.rgb")) and not (tmp_path / "frames.rgb").exists()
+
+
 def test_more_gpus_than_frames(tmp_path, fake_worker, monkeypatch):
     """Shards with an empty frame range: a raw segment of zero bytes joins as nothing; an encoded shard starts no FFmpeg
     and leaves no segment, and the concat join takes the segments that exist."""

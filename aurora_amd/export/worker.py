@@ -132,8 +132,11 @@ def _export(cfg, exporter_mod) -> None:
     if "hip_device" in vs and vs.get("hip_bind_numa", True):
         # one of several workers on a multi-GPU node: keep this process (and the pinned frame ring it is about to
         # allocate) on the socket its GPU hangs off
-        from aurora_amd import _lib, sharding
-        sharding.bind_near_device(_lib.load(), int(vs.get("hip_device") or 0))
+        from aurora_amd import sharding
+        dev = int(vs.get("hip_device") or 0)
+        if not sharding.bind_near_device(None, dev)["bus_id"]:        # sysfs first: no HIP call before the binding
+            from aurora_amd import _lib
+            sharding.bind_near_device(_lib.load(), dev)
     ex = exporter_mod.Exporter(**exporter_kwargs(cfg))
     raw_out = cfg.get("hip_raw_out")
     try:

@@ -149,6 +149,49 @@ def device_numa(bus_id: str, sysfs: str = "/sys/bus/pci/devices"):
     return (node if node >= 0 else None), cpus
 
 
+def pci_bus_id_from_sysfs(device: int, kfd: str = "/sys/class/kfd/kfd/topology/nodes", env=None):
+    """PCI address ``dddd:bb:dd.f`` of HIP device ``device`` WITHOUT touching the HIP runtime: the GPU nodes of the KFD
+    topology in node order (``simd_count`` > 0; ``location_id`` = bus << 8 | device << 3 | function, ``domain``), filtered
+    the way the runtime filters them -- ``ROCR_VISIBLE_DEVICES`` first, then ``HIP_VISIBLE_DEVICES`` /
+    ``CUDA_VISIBLE_DEVICES`` on what is left (integer lists only; UUID forms return None and the caller asks HIP).
+    None when the host does not show the topology."""
+    env = os.environ if env is None else env
+    try:
+        nodes = sorted((n for n in os.listdir(kfd) if n.isdigit()), key=int)
+    except OSError:
+        return None
+    gpus = []
+    for n in nodes:
+        props = {}
+        try:
+            with open(os.path.join(kfd, n, "properties")) as fh:
+                for line in fh:
+                    k, _, v = line.strip().partition(" ")
+                    if v.strip().lstrip("-").isdigit():
+                        props[k] = int(v)
+        except OSError:
+            continue
+        if props.get("simd_count", 0) > 0:
+            gpus.append(props)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        val = env.get(var)
+        if val is None or (var == "CUDA_VISIBLE_DEVICES" and env.get("HIP_VISIBLE_DEVICES") is not None):
+            continue
+        toks = [t.strip() for t in val.split(",") if t.strip()]
+        if not all(t.isdigit() for t in toks):
+            return None
+        picked = []
+        for t in toks:
+            if int(t) >= len(gpus):
+                break                         # the runtime stops at the first index it cannot resolve
+            picked.append(gpus[int(t)])
+        gpus = picked
+    if not (0 <= int(device) < len(gpus)) or "location_id" not in gpus[int(device)]:
+        return None
+    loc, dom = gpus[int(device)]["location_id"], gpus[int(device)].get("domain", 0)
+    return "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+
+
 def _bind_other_threads(cpus) -> int:
     """Applies the affinity mask to the process's other threads; returns how many took it (a thread may exit meanwhile)."""
     n = 0
@@ -169,23 +212,33 @@ def _bind_other_threads(cpus) -> int:
     return n
 
 
-def bind_near_device(lib, device: int, sysfs: str = "/sys/bus/pci/devices"):
+def bind_near_device(lib, device: int, sysfs: str = "/sys/bus/pci/devices",
+                     kfd: str | None = "/sys/class/kfd/kfd/topology/nodes"):
     """Restricts EVERY thread of the calling process to the CPUs next to HIP device ``device`` (those it is allowed to
     use anyway).  Asking for the device's PCI address initialises the HIP runtime, and callers have usually set the device
     or started a process group by then, so helper threads (HIP, RCCL, torch) already exist: ``sched_setaffinity(0, ..)``
     would bind the calling thread only, so the mask is applied to every task under ``/proc/self/task``; threads started
     later inherit it from their creator.  What was allocated before the call stays where it is -- call this before the
-    pinned frame ring is allocated (the workers and ``bench.py`` do).  Returns a dict describing what was done; never
-    raises: a host that does not expose the topology is left alone."""
+    pinned frame ring is allocated (the workers and ``bench.py`` do).  ``lib`` = None: only the KFD topology in sysfs is
+    asked (``pci_bus_id_from_sysfs``: no HIP call at all), which lets a rank bind itself before the runtime starts and
+    allocates anything; with a library the sysfs route is still tried first.  Returns a dict describing what was done;
+    never raises: a host that does not expose the topology is left alone."""
     import ctypes as C
     info = {"device": int(device), "bus_id": None, "numa_node": None, "bound_cpus": 0}
-    buf = C.create_string_buffer(64)
-    try:
-        if lib.aur_device_pci_bus_id(int(device), buf, 64) != 0:
+    bus = pci_bus_id_from_sysfs(device, kfd) if kfd else None
+    if bus is None:
+        if lib is None:
             return info
-    except Exception:
-        return info
-    info["bus_id"] = buf.value.decode("ascii", "ignore")
+        buf = C.create_string_buffer(64)
+        try:
+            if lib.aur_device_pci_bus_id(int(device), buf, 64) != 0:
+                return info
+        except Exception:
+            return info
+        bus = buf.value.decode("ascii", "ignore")
+    else:
+        info["via"] = "sysfs"
+    info["bus_id"] = bus
     node, cpus = device_numa(info["bus_id"], sysfs)
     info["numa_node"] = node
     if node is None or not cpus or not hasattr(os, "sched_setaffinity"):

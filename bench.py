@@ -186,6 +186,10 @@ def main():
     # one rank per GPU; BENCH_DIST_BACKEND=gloo lets several ranks share a card for rehearsals on a 1-GPU box
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     dev_index = local_rank % max(1, torch.cuda.device_count())
+    # before the HIP runtime starts (device_count does not start it): this rank and every thread it will ever have on the
+    # CPUs next to its GPU, from the KFD topology in sysfs; hosts that hide it are handled after the runtime is up
+    from aurora_amd import sharding as _sh
+    early = _sh.bind_near_device(None, dev_index)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
@@ -201,7 +205,7 @@ def main():
 
     eng = get_engine(dev_index)
     # threads and the pinned frame ring of this rank on the socket its GPU hangs off (a no-op where the host hides it)
-    placement = sharding.bind_near_device(eng.lib, dev_index)
+    placement = early if early["bus_id"] else sharding.bind_near_device(eng.lib, dev_index)
     sr, fps, W, H = args.sample_rate, args.fps, args.width, args.height
     frame_bytes = W * H * 3
     if args.batch <= 0:

@@ -304,6 +304,27 @@ def test_numa_placement_helpers(tmp_path):
         os.sched_setaffinity(0, before)
         sharding._bind_other_threads(before)
         stop.set()
+    # the same without any library: the KFD topology names the GPU's PCI address (no HIP call before the binding)
+    kfd = tmp_path / "kfd"
+    for i, (simd, loc) in enumerate([(0, 0), (1024, 0x0d00), (1024, 0xc100)]):
+        (kfd / str(i)).mkdir(parents=True)
+        (kfd / str(i) / "properties").write_text(f"cpu_cores_count 8\nsimd_count {simd}\nlocation_id {loc}\ndomain 0\n")
+    assert sharding.pci_bus_id_from_sysfs(1, str(kfd), {}) == "0000:c1:00.0"
+    assert sharding.pci_bus_id_from_sysfs(0, str(kfd), {"ROCR_VISIBLE_DEVICES": "1"}) == "0000:c1:00.0"
+    assert sharding.pci_bus_id_from_sysfs(0, str(kfd), {"HIP_VISIBLE_DEVICES": "1", "CUDA_VISIBLE_DEVICES": "0"}) == "0000:c1:00.0"
+    assert sharding.pci_bus_id_from_sysfs(2, str(kfd), {}) is None
+    assert sharding.pci_bus_id_from_sysfs(0, str(kfd), {"ROCR_VISIBLE_DEVICES": "GPU-1234"}) is None
+    assert sharding.pci_bus_id_from_sysfs(0, str(tmp_path / "nokfd"), {}) is None
+    hidden = {k: os.environ.pop(k) for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")
+              if k in os.environ}
+    try:
+        info = sharding.bind_near_device(None, 1, str(tmp_path), str(kfd))
+        assert info["bus_id"] == "0000:c1:00.0" and info["via"] == "sysfs" and info["bound_cpus"] == 1
+        assert os.sched_getaffinity(0) == {allowed[0]}
+    finally:
+        os.sched_setaffinity(0, before)
+        os.environ.update(hidden)
+    assert sharding.bind_near_device(None, 0, str(tmp_path), str(tmp_path / "nokfd"))["bus_id"] is None
     (dev / "numa_node").write_text("-1\n")                      # virtual machines
     assert sharding.bind_near_device(_Lib(b"0000:c1:00.0"), 0, str(tmp_path))["bound_cpus"] == 0
     assert os.sched_getaffinity(0) == before

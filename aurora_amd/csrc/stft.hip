@@ -54,6 +54,15 @@ namespace {
 #ifndef AUR_STFT_WIDE_STORES
 #define AUR_STFT_WIDE_STORES 0         // 1: spectrum rows leave through an LDS stage as dwordx4 stores -- measured SLOWER (below)
 #endif
+#ifndef AUR_STFT_WIN_REGS
+#define AUR_STFT_WIN_REGS 1            // 1: this lane's 16 window pairs live in registers across the frame loop (32 VGPRs)
+#endif
+#ifndef AUR_STFT_TW2_REGS
+#define AUR_STFT_TW2_REGS 12           // N: the first N of the 15 W64^(r q) twiddles of pass 2 live in registers (4 VGPRs each).
+                                       // With the window in registers too the kernel takes 242 - 256 VGPRs (two waves per SIMD,
+                                       // no scratch) and reads the LDS 19 times less per frame: 0.767 against 0.791 ms
+                                       // (profiles/r03_stft_lesions.txt); all 15 would spill
+#endif
 #ifndef AUR_STFT_MID_AT
 #define AUR_STFT_MID_AT 2              // unpack slot before which the next block's loads are issued: half of v[] is dead there,
                                        // so the 32 load registers cost no extra pressure (0: before the unpack)
@@ -326,7 +335,8 @@ __device__ __forceinline__ float block_meanabs(const v2f (&cur)[8], int lane, fl
 // partner of v[p].  Lane 0 (whose bins 64 j pair among themselves) reads b_0 = 128 instead: v[8 + s] = Z[128 + 256 s].
 template <bool ZT = false>
 __device__ __forceinline__ void fft_packed(const v2f (&prv)[8], const v2f (&cur)[8], int lane,
-                                           const Tables& T, double* xb_, cd (&v)[16]) {
+                                           const Tables& T, double* xb_, cd (&v)[16], const v2f* wreg = nullptr,
+                                           const cd* tw2reg = nullptr) {
     // volatile: keeps one ds_read_b64 / ds_write_b64 per element.  Merged into ds_read2_b64 / ds_write2_b64 the
     // accesses fall back to 32-bank addressing (half the LDS rate) and the padded rows conflict two ways.
     typedef __attribute__((address_space(3))) volatile double lds_vdouble;
@@ -335,12 +345,12 @@ __device__ __forceinline__ void fft_packed(const v2f (&prv)[8], const v2f (&cur)
     // z[l + 64 j] = (x[2n] w[2n], x[2n+1] w[2n+1])
 #pragma unroll
     for (int j = 0; j < (ZT ? 7 : 8); ++j) {
-        const v2f xw = prv[j] * T.win[lane + 64 * j];
+        const v2f xw = prv[j] * (wreg ? wreg[j] : T.win[lane + 64 * j]);
         v[j] = cd{(double)xw.x, (double)xw.y};
     }
 #pragma unroll
     for (int j = 0; j < (ZT ? 7 : 8); ++j) {
-        const v2f xw = cur[j] * T.win[lane + 64 * (j + 8)];
+        const v2f xw = cur[j] * (wreg ? wreg[j + 8] : T.win[lane + 64 * (j + 8)]);
         v[j + 8] = cd{(double)xw.x, (double)xw.y};
     }
     if (ZT) v[7] = v[15] = cd{0.0, 0.0};
@@ -371,7 +381,7 @@ __device__ __forceinline__ void fft_packed(const v2f (&prv)[8], const v2f (&cur)
 #pragma unroll
     for (int i = 1; i < 16; ++i) {
         const int q = (i >> 2) + 4 * (i & 3);
-        v[i] = cmul(v[i], T.tw2[hi2 * kTw2Stride + q]);
+        v[i] = cmul(v[i], (tw2reg && i <= AUR_STFT_TW2_REGS) ? tw2reg[i] : T.tw2[hi2 * kTw2Stride + q]);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) xb[lo4 + 16 * ((i >> 2) + 4 * (i & 3)) + 256 * hi2] = v[i].x;
@@ -665,6 +675,17 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     mags_zero(pmag);
 #endif
     cd v[16];
+    cd tw2reg[16];
+    if (AUR_STFT_TW2_REGS) {
+#pragma unroll
+        for (int i = 1; i <= AUR_STFT_TW2_REGS; ++i)
+            tw2reg[i] = T.tw2[(lane >> 4) * kTw2Stride + ((i >> 2) + 4 * (i & 3))];
+    }
+    v2f wreg[16];
+    if (AUR_STFT_WIN_REGS) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wreg[j] = T.win[lane + 64 * j];
+    }
 
     // Analyzer.buffer starts at zero (analysis.py:14); a chunk that starts inside the track first replays frame
     // c0 - 1 (the halo) to rebuild Analyzer.prev_mag, storing nothing.
@@ -694,7 +715,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
                                                           srs, 8 * lane + 512 * jj, 0, 0);
             }
         }
-        fft_packed<ZT>(prv, cur, lane, T, xb, v);
+        fft_packed<ZT>(prv, cur, lane, T, xb, v, AUR_STFT_WIN_REGS ? wreg : nullptr,
+                       AUR_STFT_TW2_REGS ? tw2reg : nullptr);
         RawBlock<C> nxt;
         float lg0 = 0.0f, lg1 = 0.0f;
         // the frame's spectrum row as a buffer resource (an empty one when nothing is stored: logspec may be NULL)

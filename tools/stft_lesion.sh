@@ -40,6 +40,10 @@ if [ "$1" = build ]; then
       w8)    extra="-DAUR_STFT_WAVES_PER_WG=8" ;;
       mid6)  extra="-DAUR_STFT_MID_AT=6" ;;
       mid0)  extra="-DAUR_STFT_MID_AT=0" ;;
+      ldstab) extra="-DAUR_STFT_WIN_REGS=0 -DAUR_STFT_TW2_REGS=0" ;;
+      winreg) extra="-DAUR_STFT_WIN_REGS=1 -DAUR_STFT_TW2_REGS=0" ;;
+      wintw7) extra="-DAUR_STFT_WIN_REGS=1 -DAUR_STFT_TW2_REGS=7" ;;
+      tw10)   extra="-DAUR_STFT_WIN_REGS=0 -DAUR_STFT_TW2_REGS=10" ;;
       narrow) extra="-DAUR_STFT_WIDE_STORES=0" ;;
       widew3) extra="-DAUR_STFT_WAVES_PER_SIMD=3 -DAUR_STFT_WAVES_PER_WG=12" ;;
       widem4) extra="-DAUR_STFT_MID_AT=4" ;;

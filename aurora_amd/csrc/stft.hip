@@ -63,6 +63,9 @@ namespace {
                                        // no scratch) and reads the LDS 19 times less per frame: 0.767 against 0.791 ms
                                        // (profiles/r03_stft_lesions.txt); all 15 would spill
 #endif
+#ifndef AUR_STFT_TW1_REGS
+#define AUR_STFT_TW1_REGS 0            // N: the first N of the 15 W1024^(l k1) twiddles of pass 1 in registers (experiment)
+#endif
 #ifndef AUR_STFT_MID_AT
 #define AUR_STFT_MID_AT 2              // unpack slot before which the next block's loads are issued: half of v[] is dead there,
                                        // so the 32 load registers cost no extra pressure (0: before the unpack)
@@ -336,7 +339,7 @@ __device__ __forceinline__ float block_meanabs(const v2f (&cur)[8], int lane, fl
 template <bool ZT = false>
 __device__ __forceinline__ void fft_packed(const v2f (&prv)[8], const v2f (&cur)[8], int lane,
                                            const Tables& T, double* xb_, cd (&v)[16], const v2f* wreg = nullptr,
-                                           const cd* tw2reg = nullptr) {
+                                           const cd* tw2reg = nullptr, const cd* tw1reg = nullptr) {
     // volatile: keeps one ds_read_b64 / ds_write_b64 per element.  Merged into ds_read2_b64 / ds_write2_b64 the
     // accesses fall back to 32-bank addressing (half the LDS rate) and the padded rows conflict two ways.
     typedef __attribute__((address_space(3))) volatile double lds_vdouble;
@@ -361,7 +364,7 @@ __device__ __forceinline__ void fft_packed(const v2f (&prv)[8], const v2f (&cur)
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) {
         const int i = 4 * (k1 & 3) + (k1 >> 2);     // register that holds output k1 of dft16
-        v[i] = cmul(v[i], T.tw1[64 * (k1 - 1)]);
+        v[i] = cmul(v[i], (tw1reg && k1 <= AUR_STFT_TW1_REGS) ? tw1reg[k1] : T.tw1[64 * (k1 - 1)]);
     }
     const int lo4 = lane & 15, hi2 = lane >> 4;
 #pragma unroll
@@ -675,6 +678,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     mags_zero(pmag);
 #endif
     cd v[16];
+    cd tw1reg[16];
+    if (AUR_STFT_TW1_REGS) {
+#pragma unroll
+        for (int k1 = 1; k1 <= AUR_STFT_TW1_REGS; ++k1) tw1reg[k1] = T.tw1[64 * (k1 - 1)];
+    }
     cd tw2reg[16];
     if (AUR_STFT_TW2_REGS) {
 #pragma unroll
@@ -716,7 +724,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
             }
         }
         fft_packed<ZT>(prv, cur, lane, T, xb, v, AUR_STFT_WIN_REGS ? wreg : nullptr,
-                       AUR_STFT_TW2_REGS ? tw2reg : nullptr);
+                       AUR_STFT_TW2_REGS ? tw2reg : nullptr, AUR_STFT_TW1_REGS ? tw1reg : nullptr);
         RawBlock<C> nxt;
         float lg0 = 0.0f, lg1 = 0.0f;
         // the frame's spectrum row as a buffer resource (an empty one when nothing is stored: logspec may be NULL)

@@ -57,11 +57,10 @@ namespace {
 #ifndef AUR_STFT_WIN_REGS
 #define AUR_STFT_WIN_REGS 1            // 1: this lane's 16 window pairs live in registers across the frame loop (32 VGPRs)
 #endif
-#ifndef AUR_STFT_TW2_REGS
-#define AUR_STFT_TW2_REGS 12           // N: the first N of the 15 W64^(r q) twiddles of pass 2 live in registers (4 VGPRs each).
-                                       // With the window in registers too the kernel takes 242 - 256 VGPRs (two waves per SIMD,
-                                       // no scratch) and reads the LDS 19 times less per frame: 0.767 against 0.791 ms
-                                       // (profiles/r03_stft_lesions.txt); all 15 would spill
+#ifndef AUR_STFT_TW3_REGS
+#define AUR_STFT_TW3_REGS 1            // 1: the twelve W64^(r q) twiddles of pass 3 live in registers (48 VGPRs).  With the
+                                       // window in registers too the kernel fills its 256 VGPRs (two waves per SIMD, no scratch)
+                                       // and reads the LDS 31 times less per frame (profiles/r03_stft_lesions.txt)
 #endif
 #ifndef AUR_STFT_TW1_REGS
 #define AUR_STFT_TW1_REGS 0            // N: the first N of the 15 W1024^(l k1) twiddles of pass 1 in registers (experiment)
@@ -132,28 +131,72 @@ __device__ __forceinline__ void radix4_z13(cd& x0, cd& x1, cd& x2, cd& x3) {
     x3 = t1;
 }
 
+// Second-stage butterflies of dft16 with the W16^(b c) twiddles folded into their additions (fused multiply-adds with
+// constant factors): the products by sqrt(1/2) ride in the sums that consume them, and a pair of full twiddles
+// cos (1 - i tan) / sin (1 - i cot) leaves its common cosine (sine) to the four output sums.  y_b = T[b][c] in, X[c + 4 d] out
+// in the same registers.  22 + 20 + 22 float64 instructions against 28 + 24 + 28 for "twiddle, then radix-4".
+constexpr double kC1 = 0.92387953251128673848;    // cos(pi/8)
+constexpr double kS1 = 0.38268343236508978178;    // sin(pi/8)
+constexpr double kH = 0.70710678118654752440;     // sqrt(1/2)
+constexpr double kT8 = 0.41421356237309504880;    // tan(pi/8)
+constexpr double kCT8 = 2.41421356237309504880;   // cot(pi/8)
+
+// c = 1: x1 = W^1 y1 = C1 (1 - i T8) y1,  x2 = W^2 y2 = H (1 - i) y2,  x3 = W^3 y3 = S1 (1 - i CT8) y3
+__device__ __forceinline__ void radix4_tw1(cd& y0, cd& y1, cd& y2, cd& y3) {
+    const cd u2 = {y2.x + y2.y, y2.y - y2.x};
+    const cd t0 = {fma(kH, u2.x, y0.x), fma(kH, u2.y, y0.y)};
+    const cd t1 = {fma(-kH, u2.x, y0.x), fma(-kH, u2.y, y0.y)};
+    const cd p1 = {fma(kT8, y1.y, y1.x), fma(-kT8, y1.x, y1.y)};
+    const cd p3 = {fma(kCT8, y3.y, y3.x), fma(-kCT8, y3.x, y3.y)};
+    const cd s = {fma(kT8, p3.x, p1.x), fma(kT8, p3.y, p1.y)};      // (x1 + x3) / C1
+    const cd d = {fma(-kT8, p3.x, p1.x), fma(-kT8, p3.y, p1.y)};    // (x1 - x3) / C1
+    y0 = cd{fma(kC1, s.x, t0.x), fma(kC1, s.y, t0.y)};
+    y1 = cd{fma(kC1, d.y, t1.x), fma(-kC1, d.x, t1.y)};
+    y2 = cd{fma(-kC1, s.x, t0.x), fma(-kC1, s.y, t0.y)};
+    y3 = cd{fma(-kC1, d.y, t1.x), fma(kC1, d.x, t1.y)};
+}
+
+// c = 2: x1 = W^2 y1 = H (1 - i) y1,  x2 = W^4 y2 = -i y2,  x3 = W^6 y3 = H (-1 - i) y3
+__device__ __forceinline__ void radix4_tw2(cd& y0, cd& y1, cd& y2, cd& y3) {
+    const cd t0 = {y0.x + y2.y, y0.y - y2.x};
+    const cd t1 = {y0.x - y2.y, y0.y + y2.x};
+    const cd u1 = {y1.x + y1.y, y1.y - y1.x};
+    const double m3 = y3.y - y3.x, q3 = y3.x + y3.y;                 // x3 = H (m3, -q3)
+    const cd s = {u1.x + m3, u1.y - q3};                             // (x1 + x3) / H
+    const cd d = {u1.x - m3, u1.y + q3};                             // (x1 - x3) / H
+    y0 = cd{fma(kH, s.x, t0.x), fma(kH, s.y, t0.y)};
+    y1 = cd{fma(kH, d.y, t1.x), fma(-kH, d.x, t1.y)};
+    y2 = cd{fma(-kH, s.x, t0.x), fma(-kH, s.y, t0.y)};
+    y3 = cd{fma(-kH, d.y, t1.x), fma(kH, d.x, t1.y)};
+}
+
+// c = 3: x1 = W^3 y1 = S1 (1 - i CT8) y1,  x2 = W^6 y2 = H (-1 - i) y2,  x3 = W^9 y3 = -C1 (1 - i T8) y3
+__device__ __forceinline__ void radix4_tw3(cd& y0, cd& y1, cd& y2, cd& y3) {
+    const double m2 = y2.y - y2.x, q2 = y2.x + y2.y;                 // x2 = H (m2, -q2)
+    const cd t0 = {fma(kH, m2, y0.x), fma(-kH, q2, y0.y)};
+    const cd t1 = {fma(-kH, m2, y0.x), fma(kH, q2, y0.y)};
+    const cd p1 = {fma(kCT8, y1.y, y1.x), fma(-kCT8, y1.x, y1.y)};
+    const cd p3 = {fma(kT8, y3.y, y3.x), fma(-kT8, y3.x, y3.y)};
+    const cd s = {fma(-kCT8, p3.x, p1.x), fma(-kCT8, p3.y, p1.y)};   // (x1 + x3) / S1
+    const cd d = {fma(kCT8, p3.x, p1.x), fma(kCT8, p3.y, p1.y)};     // (x1 - x3) / S1
+    y0 = cd{fma(kS1, s.x, t0.x), fma(kS1, s.y, t0.y)};
+    y1 = cd{fma(kS1, d.y, t1.x), fma(-kS1, d.x, t1.y)};
+    y2 = cd{fma(-kS1, s.x, t0.x), fma(-kS1, s.y, t0.y)};
+    y3 = cd{fma(-kS1, d.y, t1.x), fma(kS1, d.x, t1.y)};
+}
+
 // In-register 16-point forward DFT.  Input v[j], j = 4a + b.  Output X[k], k = c + 4d, is left in v[4c + d].
 // ZT: inputs v[7] and v[15] are zero (pass 1 of a frame whose blocks end in at least 128 zeros).
 template <bool ZT = false>
 __device__ __forceinline__ void dft16(cd (&v)[16]) {
-    constexpr double C1 = 0.92387953251128673848;   // cos(pi/8)
-    constexpr double S1 = 0.38268343236508978178;   // sin(pi/8)
-    constexpr double H = 0.70710678118654752440;    // sqrt(1/2)
 #pragma unroll
     for (int b = 0; b < (ZT ? 3 : 4); ++b) radix4(v[b], v[4 + b], v[8 + b], v[12 + b]);
     if (ZT) radix4_z13(v[3], v[7], v[11], v[15]);
-    // now v[4c + b] = T[b][c]; multiply by W16^(b c)
-    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], cd{C1, -S1});                                  // W^1
-    v[4 * 2 + 1] = cd{H * (v[4 * 2 + 1].x + v[4 * 2 + 1].y), H * (v[4 * 2 + 1].y - v[4 * 2 + 1].x)};   // W^2
-    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], cd{S1, -C1});                                  // W^3
-    v[4 * 1 + 2] = cd{H * (v[4 * 1 + 2].x + v[4 * 1 + 2].y), H * (v[4 * 1 + 2].y - v[4 * 1 + 2].x)};   // W^2
-    v[4 * 2 + 2] = mul_mi(v[4 * 2 + 2]);                                             // W^4 = -i
-    v[4 * 3 + 2] = cd{H * (v[4 * 3 + 2].y - v[4 * 3 + 2].x), -H * (v[4 * 3 + 2].x + v[4 * 3 + 2].y)};  // W^6
-    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], cd{S1, -C1});                                  // W^3
-    v[4 * 2 + 3] = cd{H * (v[4 * 2 + 3].y - v[4 * 2 + 3].x), -H * (v[4 * 2 + 3].x + v[4 * 2 + 3].y)};  // W^6
-    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], cd{-C1, S1});                                  // W^9
-#pragma unroll
-    for (int c = 0; c < 4; ++c) radix4(v[4 * c + 0], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
+    // now v[4c + b] = T[b][c]; the radix-4 over b of row c takes its inputs times W16^(b c)
+    radix4(v[0], v[1], v[2], v[3]);
+    radix4_tw1(v[4], v[5], v[6], v[7]);
+    radix4_tw2(v[8], v[9], v[10], v[11]);
+    radix4_tw3(v[12], v[13], v[14], v[15]);
 }
 
 // DPP move: lanes whose row is masked off receive 0 (the identity of the sums and of the maxima of values >= 0 below)
@@ -339,7 +382,7 @@ __device__ __forceinline__ float block_meanabs(const v2f (&cur)[8], int lane, fl
 template <bool ZT = false>
 __device__ __forceinline__ void fft_packed(const v2f (&prv)[8], const v2f (&cur)[8], int lane,
                                            const Tables& T, double* xb_, cd (&v)[16], const v2f* wreg = nullptr,
-                                           const cd* tw2reg = nullptr, const cd* tw1reg = nullptr) {
+                                           const cd* tw3reg = nullptr, const cd* tw1reg = nullptr) {
     // volatile: keeps one ds_read_b64 / ds_write_b64 per element.  Merged into ds_read2_b64 / ds_write2_b64 the
     // accesses fall back to 32-bank addressing (half the LDS rate) and the padded rows conflict two ways.
     typedef __attribute__((address_space(3))) volatile double lds_vdouble;
@@ -379,13 +422,9 @@ __device__ __forceinline__ void fft_packed(const v2f (&prv)[8], const v2f (&cur)
 #pragma unroll
     for (int p = 0; p < 16; ++p) v[p].y = xb[(hi2 + 4 * p) + 66 * lo4];
     wave_sync();
-    // pass 2: radix-16 over p (lane = k1 + 16 r), twiddle W64^(r q), transpose through LDS
+    // pass 2: radix-16 over p (lane = k1 + 16 r), transpose through LDS; the twiddle W64^(r q) waits behind the
+    // transpose, where r is the register index and r = 0 needs none: 12 products per lane instead of 15
     dft16(v);
-#pragma unroll
-    for (int i = 1; i < 16; ++i) {
-        const int q = (i >> 2) + 4 * (i & 3);
-        v[i] = cmul(v[i], (tw2reg && i <= AUR_STFT_TW2_REGS) ? tw2reg[i] : T.tw2[hi2 * kTw2Stride + q]);
-    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) xb[lo4 + 16 * ((i >> 2) + 4 * (i & 3)) + 256 * hi2] = v[i].x;
     wave_sync();
@@ -407,9 +446,17 @@ __device__ __forceinline__ void fft_packed(const v2f (&prv)[8], const v2f (&cur)
     for (int i = 0; i < 4; ++i) v[12 + i].y = xb[T.b1 + 256 * i];
     wave_sync();
     // pass 3: radix-4 over r.  Position k1 + 16 q + 256 r of the exchange holds pass-2 output q of lane k1 + 16 r;
-    // the radix-4 over r of the group at base k1 + 16 q yields Z[base + 256 s], s < 4.
+    // the radix-4 over r of the group at base k1 + 16 q, inputs times W64^(r q), yields Z[base + 256 s], s < 4.
+    // Group g of a lane sits at base lane, lane + 64, b0, b1: q = (base >> 4) & 15 is a per-lane constant, so the
+    // twelve twiddles are loop invariants (tw3reg: registers of the frame kernel; else read from the LDS table).
 #pragma unroll
-    for (int g = 0; g < 4; ++g) radix4(v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    for (int g = 0; g < 4; ++g) {
+        const int q = ((g == 0 ? lane : g == 1 ? lane + 64 : g == 2 ? T.b0 : T.b1) >> 4) & 15;
+#pragma unroll
+        for (int r = 1; r < 4; ++r)
+            v[4 * g + r] = cmul(v[4 * g + r], tw3reg ? tw3reg[3 * g + r - 1] : T.tw2[r * kTw2Stride + q]);
+        radix4(v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    }
 }
 
 // |X| in float32 from |X|^2 in float64: |X|^2 rounded to float32 (relative 2^-24; never outside the float32 range
@@ -683,11 +730,14 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
 #pragma unroll
         for (int k1 = 1; k1 <= AUR_STFT_TW1_REGS; ++k1) tw1reg[k1] = T.tw1[64 * (k1 - 1)];
     }
-    cd tw2reg[16];
-    if (AUR_STFT_TW2_REGS) {
+    cd tw3reg[12];                        // W64^(r q_g), g < 4, r = 1..3 (fft_packed, pass 3)
+    if (AUR_STFT_TW3_REGS) {
 #pragma unroll
-        for (int i = 1; i <= AUR_STFT_TW2_REGS; ++i)
-            tw2reg[i] = T.tw2[(lane >> 4) * kTw2Stride + ((i >> 2) + 4 * (i & 3))];
+        for (int g = 0; g < 4; ++g) {
+            const int q = ((g == 0 ? lane : g == 1 ? lane + 64 : g == 2 ? T.b0 : T.b1) >> 4) & 15;
+#pragma unroll
+            for (int r = 1; r < 4; ++r) tw3reg[3 * g + r - 1] = T.tw2[r * kTw2Stride + q];
+        }
     }
     v2f wreg[16];
     if (AUR_STFT_WIN_REGS) {
@@ -724,7 +774,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
             }
         }
         fft_packed<ZT>(prv, cur, lane, T, xb, v, AUR_STFT_WIN_REGS ? wreg : nullptr,
-                       AUR_STFT_TW2_REGS ? tw2reg : nullptr, AUR_STFT_TW1_REGS ? tw1reg : nullptr);
+                       AUR_STFT_TW3_REGS ? tw3reg : nullptr, AUR_STFT_TW1_REGS ? tw1reg : nullptr);
         RawBlock<C> nxt;
         float lg0 = 0.0f, lg1 = 0.0f;
         // the frame's spectrum row as a buffer resource (an empty one when nothing is stored: logspec may be NULL)
@@ -829,9 +879,11 @@ int launch_stft_z(aur_ctx* ctx, const float* d_audio, int64_t n_samples, const i
                 int n_frames, int hop, float* d_logspec, float* d_flux_sum, float* d_meanabs, float* d_samples,
                 float* d_bandmax, hipStream_t st) {
     // frames per wave: the range is cut into k rounds of one wave per wave slot (2 per SIMD), k as small as keeps a
-    // wave at <= 64 frames: long chunks amortise the 1-frame halo, whole rounds leave no tail (216 000 frames: 53)
+    // wave at <= 128 frames: long chunks amortise the 1-frame halo, whole rounds leave no tail (216 000 frames: one
+    // round of 106; measured 0.764 ms against 0.772 for two rounds of 53, and 0.94 for 160 -- more than one round's worth
+    // per wave leaves slots idle)
     const long slots = (long)ctx->num_cus * AUR_STFT_WAVES_PER_CU;
-    const long rounds = (n_frames + slots * 64 - 1) / (slots * 64);
+    const long rounds = (n_frames + slots * 128 - 1) / (slots * 128);
     int fpw = (int)((n_frames + slots * rounds - 1) / (slots * rounds));
     if (fpw < 4) fpw = 4;
     if (ctx->stft_fpw > 0) fpw = ctx->stft_fpw;

@@ -30,17 +30,18 @@ def main():
     for _ in range(2):
         an = eng.analyze(track)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(args.reps):
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.reps + 1)]
+    evs[0].record()
+    for i in range(args.reps):
         an = eng.analyze(track)
-    e1.record()
+        evs[i + 1].record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / args.reps
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.reps))
+    ms = sum(per) / len(per)
     bytes_per_frame = 4 * 2 * min(track.hop, 1024) + 4 * 1025 + 8
     gbs = F * bytes_per_frame / (ms * 1e-3) / 1e9
     print(f"stft: {F} frames  {ms:.4f} ms/launch  {F / ms * 1e3 / 1e6:.1f} Mframes/s  {gbs:.1f} GB/s "
-          f"({gbs / 8000 * 100:.1f}% of 8 TB/s)")
+          f"({gbs / 8000 * 100:.1f}% of 8 TB/s)  median {per[len(per) // 2]:.4f}  min {per[0]:.4f}")
 
 
 if __name__ == "__main__":

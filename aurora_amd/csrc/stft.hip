@@ -62,6 +62,10 @@ namespace {
                                        // window in registers too the kernel fills its 256 VGPRs (two waves per SIMD, no scratch)
                                        // and reads the LDS 31 times less per frame (profiles/r03_stft_lesions.txt)
 #endif
+#ifndef AUR_STFT_TH_REGS
+#define AUR_STFT_TH_REGS 1             // 1: the two unpack twiddles that take a full product (0.5 W2048^lane W32^1, W32^5) are
+                                       // loop invariants in registers (8 VGPRs) instead of 8 float64 instructions per frame
+#endif
 #ifndef AUR_STFT_TW1_REGS
 #define AUR_STFT_TW1_REGS 0            // N: the first N of the 15 W1024^(l k1) twiddles of pass 1 in registers (experiment)
 #endif
@@ -105,11 +109,23 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Returns its argument through an empty asm so the compiler treats it as a new value: keeps per-frame twiddle
-// arithmetic inside the frame loop instead of hoisting 30 complex doubles into registers.
-__device__ __forceinline__ cd opaque(cd w) {
-    asm volatile("" : "+v"(w.x), "+v"(w.y));
-    return w;
+// The first operations on loop-invariant per-lane twiddles, as volatile asm: the compiler neither hoists them (it would
+// park eight more doubles in registers the frame loop does not have) nor copies their inputs (an empty asm with "+v"
+// operands kept the arithmetic in the loop at the price of four 64-bit moves per frame).
+__device__ __forceinline__ double vol_add(double a, double b) {
+    double r;
+    asm volatile("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vol_sub(double a, double b) {
+    double r;
+    asm volatile("v_add_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vol_mul(double a, double b) {
+    double r;
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
 }
 
 // forward radix-4 butterfly, outputs in natural order
@@ -199,10 +215,14 @@ __device__ __forceinline__ void dft16(cd (&v)[16]) {
     radix4_tw3(v[12], v[13], v[14], v[15]);
 }
 
-// DPP move: lanes whose row is masked off receive 0 (the identity of the sums and of the maxima of values >= 0 below)
+// DPP move for reductions whose total is read from lane 63 only: lanes without a source lane keep an unspecified value.
+// Lane 63 never is one (quad / half-row / row steps have a source in every lane; row_bcast15 feeds rows 1-3 from lane 15 of
+// the row before, row_bcast31 feeds rows 2-3 from lane 31), and what the other rows hold after the two broadcast steps never
+// reaches it: its row-2 and row-1 inputs are read in the same instruction that would overwrite them.  With all rows
+// enabled and bound_ctrl each step folds into one v_add_f32_dpp / v_max_f32_dpp (masked: a zero, a v_mov_b32_dpp and the add).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp0(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
 // Sum over the 64 lanes in the order of an xor butterfly (pairs, quads, 8, 16, 32, 64: numpy's pairwise tree for
@@ -374,13 +394,25 @@ __device__ __forceinline__ float block_meanabs(const v2f (&cur)[8], int lane, fl
     return r * (1.0f / 1024.0f);
 }
 
-// 1024-point complex FFT (float64) of the windowed, packed 2048-sample buffer [prv | cur].
-// In: prv/cur[jj] = block samples (2*lane + 128*jj, +1).
+// A block serves two frames: as the second half of the buffer in its own frame and as the first half in the next one
+// (analysis.py:19-20).  What is carried from frame to frame is the block times the FIRST half of the window, computed while
+// the block is still at hand: the packed products land in the carried registers themselves, where the hand-over
+// "previous <- current" used to be seven register moves on top of the same seven products.
+template <bool ZT>
+__device__ __forceinline__ void window_first_half(const v2f (&blk)[8], int lane, const Tables& T, const v2f* wreg,
+                                                  v2f (&pw)[8]) {
+#pragma unroll
+    for (int j = 0; j < (ZT ? 7 : 8); ++j) pw[j] = blk[j] * (wreg ? wreg[j] : T.win[lane + 64 * j]);
+}
+
+// 1024-point complex FFT (float64) of the windowed, packed 2048-sample buffer [previous block | cur].
+// In: cur[jj] = block samples (2*lane + 128*jj, +1); pw[jj] = the same samples of the previous block, already times the
+// first half of the window (float32, as buffer * window rounds them; see window_first_half).
 // Out (slot p = 4 ql + s, ql < 2, s < 4):  v[p] = Z[lane + 64 (ql + 4 s)],  v[8 + p] = Z[b_ql + 256 s] with
 // b_0 = 256 - lane, b_1 = 192 - lane, i.e. v[8 + 4 ql + (3 - s)] = Z[1024 - (lane + 64 (ql + 4 s))], the unpack
 // partner of v[p].  Lane 0 (whose bins 64 j pair among themselves) reads b_0 = 128 instead: v[8 + s] = Z[128 + 256 s].
 template <bool ZT = false>
-__device__ __forceinline__ void fft_packed(const v2f (&prv)[8], const v2f (&cur)[8], int lane,
+__device__ __forceinline__ void fft_packed(const v2f (&pw)[8], const v2f (&cur)[8], int lane,
                                            const Tables& T, double* xb_, cd (&v)[16], const v2f* wreg = nullptr,
                                            const cd* tw3reg = nullptr, const cd* tw1reg = nullptr) {
     // volatile: keeps one ds_read_b64 / ds_write_b64 per element.  Merged into ds_read2_b64 / ds_write2_b64 the
@@ -390,10 +422,7 @@ __device__ __forceinline__ void fft_packed(const v2f (&prv)[8], const v2f (&cur)
     // window in float32 exactly as the reference (buffer * window, analysis.py:25), then widen and pack:
     // z[l + 64 j] = (x[2n] w[2n], x[2n+1] w[2n+1])
 #pragma unroll
-    for (int j = 0; j < (ZT ? 7 : 8); ++j) {
-        const v2f xw = prv[j] * (wreg ? wreg[j] : T.win[lane + 64 * j]);
-        v[j] = cd{(double)xw.x, (double)xw.y};
-    }
+    for (int j = 0; j < (ZT ? 7 : 8); ++j) v[j] = cd{(double)pw[j].x, (double)pw[j].y};
 #pragma unroll
     for (int j = 0; j < (ZT ? 7 : 8); ++j) {
         const v2f xw = cur[j] * (wreg ? wreg[j + 8] : T.win[lane + 64 * (j + 8)]);
@@ -484,11 +513,22 @@ __device__ __forceinline__ float log1p_pos(float x) {
 //   |z| = max * sqrt(fma(d, d, 1)),  d = min / max,  max = max(|re|, |im|), min = min(|re|, |im|)
 // with IEEE division and square root -- bit-identical to np.abs(complex64) on 2 000 000 random values
 // (tests/test_host_cpu.py::test_numpy_cabs_formula).  The other bins keep mag_from_sq (flux only needs rtol 1e-4).
+// sqrt of x in [1, 2], correctly rounded: v_sqrt_f32 (1 ulp) and the residual test of its two neighbours -- the steps of the
+// compiler's own IEEE expansion of sqrtf without the input scaling and the 0 / infinity handling this range never needs
+// (7 of its 16 instructions).
+__device__ __forceinline__ float sqrt_cr_1to2(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __int_as_float(__float_as_int(s) - 1), up = __int_as_float(__float_as_int(s) + 1);
+    const float rd = fmaf(-dn, s, x), ru = fmaf(-up, s, x);
+    const float r = rd <= 0.0f ? dn : s;
+    return ru > 0.0f ? up : r;
+}
+
 __device__ __forceinline__ float cabs_c64(double re_d, double im_d) {
     const float a = fabsf((float)re_d), b = fabsf((float)im_d);      // astype(complex64)
     const float mx = fmaxf(a, b), mn = fminf(a, b);
     const float d = mx > 0.0f ? mn / mx : 0.0f;                      // correctly rounded (no fast-math on this library)
-    return mx * __builtin_sqrtf(fmaf(d, d, 1.0f));
+    return mx * sqrt_cr_1to2(fmaf(d, d, 1.0f));                      // d in [0, 1]
 }
 
 // Correctly rounded log1p of a float32 x >= 0 (np.log1p at audio/analysis.py:33 is within 1-2 ulp of this: numpy's
@@ -531,7 +571,19 @@ __device__ __forceinline__ int slot_bin(int lane, int p) {
 struct Mags {
     v2f ab[8];
     float mid;
-    __device__ __forceinline__ v2f swap(int p, v2f m) { const v2f t = ab[p]; ab[p] = m; return t; }
+    // m - previous, then previous <- m as ONE 64-bit move into the register pair the previous value lived in: the tied
+    // operand keeps the pair in place, the unused operand d orders the move behind the subtraction (left to the compiler the
+    // hand-over was two v_mov_b32 per slot at the loop head).
+    // The s_nop is NOT optional: m comes out of v_sqrt_f32, and on gfx940 / gfx950 a non-transcendental VALU instruction
+    // that reads the result of a transcendental one needs one wait state in between.  The compiler's hazard recogniser
+    // inserts it for its own instructions but does not look inside an asm statement: without the nop the halo frame of a
+    // chunk (where the scheduler happened to put the move right behind the square root) handed stale magnitudes on and the
+    // first flux of every chunk was off by a few per cent (caught by test_analysis_vs_reference_fixtures).
+    __device__ __forceinline__ v2f diff(int p, v2f m) {
+        const v2f d = m - ab[p];
+        asm("s_nop 0\n\tv_mov_b64 %0, %1" : "+v"(ab[p]) : "v"(m), "v"(d));
+        return d;
+    }
     __device__ __forceinline__ float swap_mid(float m) { const float t = mid; mid = m; return t; }
 };
 
@@ -539,11 +591,11 @@ struct Mags {
 // 17 registers fewer across the whole frame for 34 LDS accesses per frame.  Build knob AUR_STFT_PMAG_LDS.
 struct MagsLds {
     float* col;          // &area[lane]
-    __device__ __forceinline__ v2f swap(int p, v2f m) {
+    __device__ __forceinline__ v2f diff(int p, v2f m) {
         const v2f t = {col[64 * (2 * p)], col[64 * (2 * p + 1)]};
         col[64 * (2 * p)] = m.x;
         col[64 * (2 * p + 1)] = m.y;
-        return t;
+        return m - t;
     }
     __device__ __forceinline__ float swap_mid(float m) { const float t = col[64 * 16]; col[64 * 16] = m; return t; }
 };
@@ -568,7 +620,8 @@ __device__ __forceinline__ v2f log1p_pos2(v2f x) {
 // It holds Z[256 s] in v[s] and Z[128 + 256 s] in v[8 + s] and wires its four slots as
 //   s = 0: (Z[0], Z[0]) -> X[0], X[1024]      s = 2: (Z[640], Z[384])   (generic kA shifted by 128)
 //   s = 1: (Z[256], Z[768])                   s = 3: (Z[896], Z[128])   (generic kA shifted by 128)
-// which costs 16 selects; X[512] = conj Z[512] = conj v[2] is the extra "mid" bin.
+// by four complex register moves executed with lane 0 alone enabled (lane0_rewire; as selects in every lane they were 32
+// v_cndmask_b32 per frame); X[512] = conj Z[512] = conj v[2], read before the moves, is the extra "mid" bin.
 // Twiddles th = 0.5 W2048^kA = wuh W32^j, j = ql + 4 s: W32^4 = (1 - i) / sqrt 2, W32^8 = -i, so only W32^1 and
 // W32^5 need a full product; T.wus equals T.wuh except in lane 0, where it carries the shift by 128 bins.
 // Returns this lane's flux partial.  When EMIT: lg0 / lg1 receive log1p|X| of bins lane and lane + 64 (band maxima),
@@ -581,24 +634,56 @@ __device__ __forceinline__ v2f log1p_pos2(v2f x) {
 // and leaves as four buffer_store_dwordx4 plus one dword -- build knob AUR_STFT_WIDE_STORES=1.  Measured 0.82 ms against
 // 0.78 ms for the direct stores (profiles/r03_stft_lesions.txt): the two extra wave-wide LDS round trips per frame cost
 // more than the twelve store instructions they save, so the direct stores stay the default.
+// Lane 0 only: v[2] <- v[10] (Z[640]), v[10] <- v[3] (Z[768]), v[3] <- v[11] (Z[896]), v[11] <- v[0] (Z[0]), after which
+// the generic wiring of the slots (A = v[s], P = v[11 - s]) reads lane 0's own pairs.  One asm block: EXEC is narrowed
+// to lane 0 and restored inside it, so the frame body stays one basic block.  The whole wave is active here (the only exit
+// above is wave-uniform).
+__device__ __forceinline__ void lane0_rewire(cd (&v)[16]) {
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "v_mov_b64 %[v2x], %[v10x]\n\t"
+        "v_mov_b64 %[v2y], %[v10y]\n\t"
+        "v_mov_b64 %[v10x], %[v3x]\n\t"
+        "v_mov_b64 %[v10y], %[v3y]\n\t"
+        "v_mov_b64 %[v3x], %[v11x]\n\t"
+        "v_mov_b64 %[v3y], %[v11y]\n\t"
+        "v_mov_b64 %[v11x], %[v0x]\n\t"
+        "v_mov_b64 %[v11y], %[v0y]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [sv] "=&s"(saved), [v2x] "+v"(v[2].x), [v2y] "+v"(v[2].y), [v10x] "+v"(v[10].x), [v10y] "+v"(v[10].y),
+          [v3x] "+v"(v[3].x), [v3y] "+v"(v[3].y), [v11x] "+v"(v[11].x), [v11y] "+v"(v[11].y)
+        : [v0x] "v"(v[0].x), [v0y] "v"(v[0].y));
+}
+
 template <bool EMIT, bool STORE_LOG, typename PM, typename MID>
-__device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const Tables& T, PM& pm,
+__device__ __forceinline__ float unpack_mag(cd (&v)[16], int lane, const Tables& T, PM& pm,
                                             const __amdgpu_buffer_rsrc_t out, float* stage, float& lg0, float& lg1,
-                                            MID&& mid_hook) {
+                                            MID&& mid_hook, const cd* threg = nullptr) {
     constexpr double H = 0.70710678118654752440;
     const bool l0 = lane == 0;
-    const cd wuh = opaque(T.wuh);
-    const cd wus = opaque(T.wus);
+    const cd wuh = T.wuh, wus = T.wus;
     cd th[8];
     th[0] = wuh;                                                       // j = 0
-    th[1] = cd{H * (wuh.x + wuh.y), H * (wuh.y - wuh.x)};              // j = 4
+    th[1] = cd{H * vol_add(wuh.x, wuh.y), H * vol_sub(wuh.y, wuh.x)};  // j = 4
     th[2] = mul_mi(wus);                                               // j = 8
-    th[3] = mul_mi(cd{H * (wus.x + wus.y), H * (wus.y - wus.x)});      // j = 12
-    th[4] = cmul(wuh, cd{kW32re1, kW32im1});                           // j = 1
-    th[5] = cmul(wuh, cd{kW32re5, kW32im5});                           // j = 5
+    th[3] = mul_mi(cd{H * vol_add(wus.x, wus.y), H * vol_sub(wus.y, wus.x)});      // j = 12
+    // cmul(wuh, W32^1) and cmul(wuh, W32^5) with their leading products kept in the loop
+    if (threg) {
+        th[4] = threg[0];
+        th[5] = threg[1];
+    } else {
+        th[4] = cd{fma(wuh.x, kW32re1, -vol_mul(wuh.y, kW32im1)), fma(wuh.x, kW32im1, vol_mul(wuh.y, kW32re1))};   // j = 1
+        th[5] = cd{fma(wuh.x, kW32re5, -vol_mul(wuh.y, kW32im5)), fma(wuh.x, kW32im5, vol_mul(wuh.y, kW32re5))};   // j = 5
+    }
     th[6] = mul_mi(th[4]);                                             // j = 9
     th[7] = mul_mi(th[5]);                                             // j = 13
     v2f fl2 = {0.0f, 0.0f};
+    // bin 512 (lane 0 owns it): X[512] = conj Z[512]; its logarithm rides with slot 0's second bin
+    const float mm = mag_from_sq(fma(v[2].x, v[2].x, v[2].y * v[2].y));
+    float lmid = 0.0f;
+    lane0_rewire(v);
     // byte offsets of the stores: bin lane + 64 j = off_a + 256 j; bin 1024 - lane - 64 j = off_b + (3840 - 256 j) with
     // off_b = 256 - 4 lane > 0; the shifted slots of lane 0 (bins off2 + 64 j and 1024 - off2 - 64 j, j = 8, 12) use
     // off_a2 = 4 off2 and off_b2 = 4 (256 - off2) + 4 (768 - 64 j)
@@ -608,11 +693,7 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
     for (int p = 0; p < 8; ++p) {
         const int ql = p >> 2, s = p & 3, j = ql + 4 * s;
         if (p == AUR_STFT_MID_AT) mid_hook();   // half of v[] is dead from here on
-        cd A = v[p], P = v[8 + 4 * ql + (3 - s)];
-        if (p == 0) P = cd{l0 ? v[0].x : P.x, l0 ? v[0].y : P.y};
-        if (p == 1) P = cd{l0 ? v[3].x : P.x, l0 ? v[3].y : P.y};
-        if (p == 2) A = cd{l0 ? v[10].x : A.x, l0 ? v[10].y : A.y};
-        if (p == 3) A = cd{l0 ? v[11].x : A.x, l0 ? v[11].y : A.y};
+        const cd A = v[p], P = v[8 + 4 * ql + (3 - s)];
         const double a = A.x, b = A.y, c = P.x, d = P.y;
         const double ex = a + c, ey = b - d;     // 2E
         const double ox = b + d, oy = c - a;     // 2O = -i (Z[kA] - conj Z[kB])
@@ -622,9 +703,16 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
         const double br = fma(0.5, ex, -tx), bi = fma(0.5, ey, -ty);
         // j < 2: bin kA = lane + 64 j is one of the displayed bins: the reference's own magnitude / log1p chain
         const v2f m = {j < 2 ? cabs_c64(ar, ai) : mag_from_sq(fma(ar, ar, ai * ai)), mag_from_sq(fma(br, br, bi * bi))};
-        fl2 += __builtin_elementwise_max(m - pm.swap(p, m), (v2f)(0.0f));
+        fl2 += __builtin_elementwise_max(pm.diff(p, m), (v2f)(0.0f));
         if (EMIT) {
-            const v2f l = j < 2 ? v2f{log1p_cr(m.x, T.lg), log1p_pos(m.y)} : log1p_pos2(m);
+            v2f l;
+            if (p == 0) {
+                const v2f lp = log1p_pos2(v2f{m.y, mm});
+                l = v2f{log1p_cr(m.x, T.lg), lp.x};
+                lmid = lp.y;
+            } else {
+                l = j < 2 ? v2f{log1p_cr(m.x, T.lg), log1p_pos(m.y)} : log1p_pos2(m);
+            }
             if (j == 0) lg0 = l.x;
             if (j == 1) lg1 = l.x;
             if (STORE_LOG) {
@@ -642,15 +730,11 @@ __device__ __forceinline__ float unpack_mag(const cd (&v)[16], int lane, const T
         }
     }
     float fl = fl2.x + fl2.y;
-    {   // bin 512 (lane 0): X[512] = conj(Z[512])
-        const cd z8 = v[2];
-        const float mm = mag_from_sq(fma(z8.x, z8.x, z8.y * z8.y));
-        if (l0) {
-            fl += fmaxf(0.0f, mm - pm.swap_mid(mm));
-            if (EMIT && STORE_LOG) {
-                if (AUR_STFT_WIDE_STORES) stage[512] = log1p_pos(mm);
-                else aur_buf_st(log1p_pos(mm), out, 4 * 512);
-            }
+    if (l0) {   // bin 512
+        fl += fmaxf(0.0f, mm - pm.swap_mid(mm));
+        if (EMIT && STORE_LOG) {
+            if (AUR_STFT_WIDE_STORES) stage[512] = lmid;
+            else aur_buf_st(lmid, out, 4 * 512);
         }
     }
     if (EMIT && STORE_LOG && AUR_STFT_WIDE_STORES) {
@@ -739,6 +823,13 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
             for (int r = 1; r < 4; ++r) tw3reg[3 * g + r - 1] = T.tw2[r * kTw2Stride + q];
         }
     }
+    // (only the zero-tail variant has the registers: it carries 7 block pairs instead of 8)
+    constexpr bool kThRegs = AUR_STFT_TH_REGS && ZT;
+    cd threg[2];                          // the same arithmetic as unpack_mag's own (bit-identical twiddles either way)
+    if (kThRegs) {
+        threg[0] = cd{fma(T.wuh.x, kW32re1, -(T.wuh.y * kW32im1)), fma(T.wuh.x, kW32im1, T.wuh.y * kW32re1)};
+        threg[1] = cd{fma(T.wuh.x, kW32re5, -(T.wuh.y * kW32im5)), fma(T.wuh.x, kW32im5, T.wuh.y * kW32re5)};
+    }
     v2f wreg[16];
     if (AUR_STFT_WIN_REGS) {
 #pragma unroll
@@ -748,15 +839,16 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     // Analyzer.buffer starts at zero (analysis.py:14); a chunk that starts inside the track first replays frame
     // c0 - 1 (the halo) to rebuild Analyzer.prev_mag, storing nothing.
     const long fstart = (c0 > 0) ? c0 - 1 : c0;
-    v2f prv[8], cur[8];
-    load_block<C, ZT>(audio, n_samp, pos, fstart - 1, hop, lane, prv);
+    v2f pw[8], cur[8];
+    load_block<C, ZT>(audio, n_samp, pos, fstart - 1, hop, lane, cur);
+    window_first_half<ZT>(cur, lane, T, AUR_STFT_WIN_REGS ? wreg : nullptr, pw);
     load_block<C, ZT>(audio, n_samp, pos, fstart, hop, lane, cur);
 
     // One frame.  STORE = false is the halo frame: transform and magnitudes only.  The next frame's block is
     // requested after the FFT, before anything of this frame is stored, and is first touched at the end of the body:
     // gfx950 counts loads and stores in one in-order counter (vmcnt), so a load issued behind the 17 spectrum stores
     // of a frame could only be waited for by draining those stores first.
-    // (Alternating the roles of prv / cur over a loop unrolled by two instead of copying 16 registers per frame was
+    // (Alternating the roles of previous / current block over a loop unrolled by two instead of handing 16 registers over was
     // measured: 27 VALU instructions fewer per frame, twice the code, 0.841 vs 0.828 ms -- not kept.)
     auto frame = [&](long f, auto store_tag) {
         constexpr bool STORE = decltype(store_tag)::value;
@@ -773,7 +865,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
                                                           srs, 8 * lane + 512 * jj, 0, 0);
             }
         }
-        fft_packed<ZT>(prv, cur, lane, T, xb, v, AUR_STFT_WIN_REGS ? wreg : nullptr,
+        fft_packed<ZT>(pw, cur, lane, T, xb, v, AUR_STFT_WIN_REGS ? wreg : nullptr,
                        AUR_STFT_TW3_REGS ? tw3reg : nullptr, AUR_STFT_TW1_REGS ? tw1reg : nullptr);
         RawBlock<C> nxt;
         float lg0 = 0.0f, lg1 = 0.0f;
@@ -783,7 +875,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
             (void*)(logspec + (row ? fo * AUR_NBINS : 0)), 0, row ? AUR_NBINS * 4 : 0, kRsrcWord3);
         float fl = unpack_mag<STORE && (LOG || BM), STORE && LOG>(
             v, lane, T, pmag, ors, xf, lg0, lg1,
-            [&]() { issue_block<C, ZT>(audio, n_samp, pos, (f + 1 < cend) ? f + 1 : -1, hop, lane, nxt); });
+            [&]() { issue_block<C, ZT>(audio, n_samp, pos, (f + 1 < cend) ? f + 1 : -1, hop, lane, nxt); },
+            kThRegs ? threg : nullptr);
         if (STORE) {
             fl = wave_sum(fl);
             if (lane == 0) flux_sum[fo] = fl;
@@ -797,8 +890,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < (ZT ? 7 : 8); ++i) prv[i] = cur[i];
+        window_first_half<ZT>(cur, lane, T, AUR_STFT_WIN_REGS ? wreg : nullptr, pw);
         mix_block<C, ZT>(nxt, cur);
     };
 
@@ -821,16 +913,16 @@ __global__ __launch_bounds__(64) void stft_buffer_kernel(const float* __restrict
     const int lane = threadIdx.x;
     const Tables T = stage_tables(window, twid, smem, lane);
     double* xb = reinterpret_cast<double*>(smem + kLdsTabBytes);
-    v2f prv[8], cur[8];
+    v2f pw[8], cur[8];
     Mags pmag;
     cd v[16];
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
-        prv[jj] = *reinterpret_cast<const v2f*>(buffer + 2 * lane + 128 * jj);
+        pw[jj] = *reinterpret_cast<const v2f*>(buffer + 2 * lane + 128 * jj) * T.win[lane + 64 * jj];
         cur[jj] = *reinterpret_cast<const v2f*>(buffer + AUR_BLOCK + 2 * lane + 128 * jj);
     }
     mags_load(pmag, prev_mag, lane);
-    fft_packed(prv, cur, lane, T, xb, v);
+    fft_packed(pw, cur, lane, T, xb, v);
     float lg0, lg1;
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)logspec, 0, AUR_NBINS * 4, kRsrcWord3);
     float fl = unpack_mag<true, true>(v, lane, T, pmag, ors, reinterpret_cast<float*>(xb), lg0, lg1, []() {});

@@ -132,7 +132,10 @@ class _Child:
                 continue
             kind = msg.get("type")
             if kind == "progress":
-                self.pct = max(self.pct, int(msg.get("pct", 0)))
+                try:
+                    self.pct = max(self.pct, int(msg.get("pct", 0)))
+                except (TypeError, ValueError):
+                    continue                                   # a malformed line must not end the reader thread
                 self._on_progress()
             elif kind == "error":
                 self.error = str(msg.get("message", "export failed"))
@@ -156,14 +159,28 @@ class _Child:
         tail = b"".join(self._err_tail).decode("utf-8", "ignore").strip()
         return f"{self.tag}: {self.error or 'worker exited with status %d' % code}" + (f"\n{tail}" if tail else "")
 
+    KILL_AFTER_S = 10.0      # grace between SIGTERM and SIGKILL for a worker that does not react (blocked in a call)
+
     def stop(self):
         """Ends the worker AND what it started (its FFmpeg would otherwise go on writing the segment the supervisor is
-        about to remove)."""
+        about to remove).  SIGTERM to the process group first; a group that is still there ``KILL_AFTER_S`` seconds later
+        gets SIGKILL, so the threads waiting for the worker always return."""
         if self.proc.poll() is None:
             try:
                 os.killpg(self.proc.pid, signal.SIGTERM)
             except (ProcessLookupError, PermissionError, AttributeError):
                 self.proc.terminate()
+            if not getattr(self, "_kill_timer", None):
+                def hard():
+                    if self.proc.poll() is None:
+                        self.reap_group()
+                        try:
+                            self.proc.kill()
+                        except OSError:
+                            pass
+                self._kill_timer = threading.Timer(self.KILL_AFTER_S, hard)
+                self._kill_timer.daemon = True
+                self._kill_timer.start()
 
     def reap_group(self):
         """After the worker has gone: nothing of its process group may be left behind (an FFmpeg that outlived it)."""

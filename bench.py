@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument("--slots", type=int, default=3, help="ring slots in flight")
     ap.add_argument("--wire", default="rgb24", choices=("rgb24", "yuv420p", "nv12"), help="wire format of the headline leg")
     ap.add_argument("--device-seconds", type=float, default=3600.0, help="track of the device-side leg (configs[4] unit)")
-    ap.add_argument("--device-steps", type=int, default=2, help="timed steps of the device-side leg (0 = skip)")
+    ap.add_argument("--device-steps", type=int, default=4, help="timed steps of the device-side leg (0 = skip)")
     ap.add_argument("--device-warmup", type=int, default=1, help="untimed steps of the device-side leg")
     ap.add_argument("--cpu-frames", type=int, default=240, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-cores CPU figure (0 = box share)")

@@ -205,6 +205,30 @@ def test_a_silent_worker_is_stopped_after_the_stall_timeout(tmp_path, fake_worke
     assert not list(tmp_path.glob("frames.seg*.rgb")) and not (tmp_path / "frames.rgb").exists()
 
 
+def test_a_worker_that_ignores_sigterm_is_killed(tmp_path, fake_worker, monkeypatch):
+    """A failing shard stops the others with SIGTERM; one that does not react (blocked in a call) gets SIGKILL after a
+    grace period, so the supervisor's waiting threads always return.  A malformed progress line does not end the reader."""
+    import time
+    monkeypatch.setattr(sharded._Child, "KILL_AFTER_S", 0.5)
+    p = tmp_path / "deaf_worker.py"
+    p.write_text("import json, signal, sys, time\ncfg = json.load(open(sys.argv[1]))\n"
+                 "r = (cfg.get('view_state') or {}).get('hip_shard', [0, 1])[0]\n"
+                 "if r == 0:\n"
+                 "    signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+                 "    print(json.dumps({'type': 'progress', 'pct': 'soon'}), flush=True)\n"
+                 "    print(json.dumps({'type': 'progress', 'pct': 3}), flush=True)\n"
+                 "    time.sleep(600)\n"
+                 "time.sleep(0.5)\n"
+                 "print(json.dumps({'type': 'error', 'message': 'boom'}), flush=True)\nsys.exit(1)\n")
+    seen = []
+    t0 = time.time()
+    with pytest.raises(RuntimeError) as ei:
+        sharded.export_sharded(_cfg(tmp_path, hip_raw_out=str(tmp_path / "frames.rgb")), 2, seen.append,
+                               worker_cmd=[sys.executable, str(p)], devices=[0])
+    assert "boom" in str(ei.value) and time.time() - t0 < 20
+    assert seen == [3]                  # the line after the malformed one was still read
+
+
 def test_more_gpus_than_frames(tmp_path, fake_worker, monkeypatch):
     """Shards with an empty frame range: a raw segment of zero bytes joins as nothing; an encoded shard starts no FFmpeg
     and leaves no segment, and the concat join takes the segments that exist."""

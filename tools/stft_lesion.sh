@@ -16,18 +16,23 @@ if [ "$1" = build ]; then
     f=$d/aurora_amd/csrc/stft.hip
     case $v in
       noexch)  python3 -c "import re,sys; s=open(sys.argv[1]).read(); s=re.sub(r'#pragma unroll\n    for \([^\n]*\) [^\n]*xb\[[^\n]*\n','',s); open(sys.argv[1],'w').write(s)" $f ;;
-      nostore) sed -i '/^ *aur_buf_st(l\.[xy], out, /d; s/if (EMIT \&\& STORE_LOG) aur_buf_st(log1p_pos(mm), out, 4 \* 512);/if (EMIT \&\& STORE_LOG \&\& mm < 0.0f) aur_buf_st(mm, out, 2048);/' $f
+      nostore) sed -i '/^ *aur_buf_st(l\.[xy], out, /d; s/else aur_buf_st(lmid, out, 4 \* 512);/else if (mm < 0.0f) aur_buf_st(lmid, out, 2048);/' $f
                sed -i 's/if (j == 0) lg0 = l.x;/lg0 += l.x + l.y;/' $f ;;
       samerow) sed -i 's/(void\*)(logspec + (row ? fo \* AUR_NBINS : 0)), 0, row ? AUR_NBINS \* 4 : 0, kRsrcWord3);/(void*)(logspec + (row ? (fo \& 1023) * AUR_NBINS : 0)), 0, row ? AUR_NBINS * 4 : 0, kRsrcWord3);/' $f ;;
       nomean)  sed -i 's/const float ma = block_meanabs(cur, lane, xf);/const float ma = cur[0].x;/' $f ;;
-      notw)    sed -i 's/v\[i\] = cmul(v\[i\], T.tw1\[64 \* (k1 - 1)\]);/v[i] = cmul(v[i], T.wuh);/; s/v\[i\] = cmul(v\[i\], T.tw2\[hi2 \* kTw2Stride + q\]);/v[i] = cmul(v[i], T.wus);/' $f ;;
-      nolog)   sed -i 's/const v2f l = j < 2 ? v2f{log1p_cr(m.x, T.lg), log1p_pos(m.y)} : log1p_pos2(m);/const v2f l = m;/' $f ;;
+      notw)    sed -i 's/v\[i\] = cmul(v\[i\], (tw1reg \&\& k1 <= AUR_STFT_TW1_REGS) ? tw1reg\[k1\] : T.tw1\[64 \* (k1 - 1)\]);/v[i] = cmul(v[i], T.wuh);/' $f ;;
+      nolog)   sed -i 's/l = j < 2 ? v2f{log1p_cr(m.x, T.lg), log1p_pos(m.y)} : log1p_pos2(m);/l = m;/; s/const v2f lp = log1p_pos2(v2f{m.y, mm});/const v2f lp = v2f{m.y, mm};/; s/l = v2f{log1p_cr(m.x, T.lg), lp.x};/l = v2f{m.x, lp.x};/' $f ;;
       nocabs)  sed -i 's/const v2f m = {j < 2 ? cabs_c64(ar, ai) : mag_from_sq(fma(ar, ar, ai \* ai)), mag_from_sq(fma(br, br, bi \* bi))};/const v2f m = {mag_from_sq(fma(ar, ar, ai * ai)), mag_from_sq(fma(br, br, bi * bi))};/' $f ;;
+      exact1)  sed -i 's/j < 2 ? cabs_c64(ar, ai)/j < 1 ? cabs_c64(ar, ai)/; s/l = j < 2 ? v2f{log1p_cr/l = j < 1 ? v2f{log1p_cr/' $f ;;   # bins 64..127 through the cheap chain
       compute) python3 -c "import re,sys; s=open(sys.argv[1]).read(); s=re.sub(r'#pragma unroll\n    for \([^\n]*\) [^\n]*xb\[[^\n]*\n','',s); open(sys.argv[1],'w').write(s)" $f
                sed -i '/^ *aur_buf_st(l\.[xy], out, /d' $f
                sed -i 's/if (j == 0) lg0 = l.x;/lg0 += l.x + l.y;/' $f
                sed -i 's/(f + 1 < cend) ? f + 1 : -1, hop, lane, nxt);/fstart, hop, lane, nxt);/' $f ;;
       noload)  sed -i 's/(f + 1 < cend) ? f + 1 : -1, hop, lane, nxt);/fstart, hop, lane, nxt);/' $f ;;
+    esac
+    case $v in
+      noexch|nostore|samerow|nomean|notw|nolog|nocabs|exact1|compute|noload)
+        if cmp -s $f $SRC/stft.hip; then echo "variant $v: the patterns of this script no longer match stft.hip" >&2; exit 1; fi ;;
     esac
     extra=""
     case $v in

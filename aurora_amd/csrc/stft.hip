@@ -789,6 +789,11 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     // and pos[f] live in scalar registers and the per-frame branches are scalar branches
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const Tables T = stage_tables(window, twid, smem, lane);
+    // The per-lane twiddles come from global memory and are first used inside the frame loop.  A use here makes the
+    // compiler wait for those loads in front of the loop; otherwise its wait-count pass, which cannot tell the first
+    // iteration from the others, puts a full s_waitcnt vmcnt(0) in front of their first use INSIDE the loop, and every frame
+    // then waits for the previous frame's spectrum stores to be acknowledged.
+    asm volatile("" ::"v"(T.wuh.x), "v"(T.wuh.y), "v"(T.wus.x), "v"(T.wus.y));
 
     double* xb = reinterpret_cast<double*>(smem + kLdsTabBytes) + wave * kXbufDoubles;   // wave-private
     float* xf = reinterpret_cast<float*>(xb);
@@ -843,6 +848,9 @@ __global__ __launch_bounds__(kWavesPerWG * 64, AUR_STFT_WAVES_PER_SIMD) void stf
     load_block<C, ZT>(audio, n_samp, pos, fstart - 1, hop, lane, cur);
     window_first_half<ZT>(cur, lane, T, AUR_STFT_WIN_REGS ? wreg : nullptr, pw);
     load_block<C, ZT>(audio, n_samp, pos, fstart, hop, lane, cur);
+    // the same for the first block (mono: the loaded registers ARE the block, first read inside the loop)
+#pragma unroll
+    for (int jj = 0; jj < (ZT ? 7 : 8); ++jj) asm volatile("" ::"v"(cur[jj]));
 
     // One frame.  STORE = false is the halo frame: transform and magnitudes only.  The next frame's block is
     // requested after the FFT, before anything of this frame is stored, and is first touched at the end of the body:

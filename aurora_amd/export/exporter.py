@@ -22,6 +22,7 @@ import ctypes as C
 import errno
 import logging
 import os
+import re
 import platform
 import shutil
 import subprocess
@@ -227,39 +228,41 @@ class HipOffscreenRenderer:
 
 # ----------------------------------------------------------------------------- ffmpeg utilities
 
-def _ffmpeg_bin() -> str:
-    """AURORA_FFMPEG, IMAGEIO_FFMPEG_EXE, imageio_ffmpeg, then PATH (exporter.py:319-341)."""
+def _ffmpeg_candidates():
+    """Where an FFmpeg binary may come from, in the reference's order of preference (exporter.py:319-341): the two
+    environment variables, then whatever the imageio_ffmpeg package ships."""
     for var in ("AURORA_FFMPEG", "IMAGEIO_FFMPEG_EXE"):
-        cand = os.environ.get(var)
-        if cand and Path(cand).exists():
-            return cand
+        yield os.environ.get(var)
     try:
         import imageio_ffmpeg
-        cand = imageio_ffmpeg.get_ffmpeg_exe()
-        if cand and Path(cand).exists():
-            return cand
+        yield imageio_ffmpeg.get_ffmpeg_exe()
     except Exception:
-        pass
-    found = shutil.which("ffmpeg")
-    if found:
-        return found
-    raise RuntimeError("FFmpeg not found. Install ffmpeg or pip install imageio-ffmpeg, "
-                       "or set AURORA_FFMPEG/IMAGEIO_FFMPEG_EXE.")
+        return
+
+
+def _ffmpeg_bin() -> str:
+    for cand in _ffmpeg_candidates():
+        if cand and os.path.exists(cand):
+            return cand
+    on_path = shutil.which("ffmpeg")
+    if on_path is None:
+        raise RuntimeError("FFmpeg not found. Install ffmpeg or pip install imageio-ffmpeg, "
+                           "or set AURORA_FFMPEG/IMAGEIO_FFMPEG_EXE.")
+    return on_path
+
+
+# a video encoder line of `ffmpeg -encoders`: " V....D libx264   H.264 / AVC ..." -> the second column
+_VIDEO_ENCODER_LINE = re.compile(r"^ V\S*[ \t]+(\S+)", re.MULTILINE)
 
 
 def _ffmpeg_encoders(ffmpeg: str) -> set:
+    """Names of the video encoders this FFmpeg offers; empty when it cannot be asked (exporter.py:344-360)."""
     try:
-        listing = subprocess.check_output([ffmpeg, "-hide_banner", "-encoders"], stderr=subprocess.STDOUT,
-                                          text=True, errors="ignore")
+        proc = subprocess.run([ffmpeg, "-hide_banner", "-encoders"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True, errors="ignore")
     except Exception:
         return set()
-    names = set()
-    for line in listing.splitlines():
-        if line.startswith(" V"):
-            cols = line.split()
-            if len(cols) > 1:
-                names.add(cols[1].strip())
-    return names
+    return set(_VIDEO_ENCODER_LINE.findall(proc.stdout)) if proc.returncode == 0 else set()
 
 
 def _ensure_ext(path: str, default_ext: str) -> str:

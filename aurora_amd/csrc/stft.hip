@@ -8,7 +8,8 @@
 // first matching loop of the ufunc) and the result is rounded to complex64, so the reference spectrum is a
 // float64 FFT of the float32 product buffer*window.  Leakage bins sit 8-9 decades below the peak of a frame,
 // which a float32 butterfly network cannot resolve (its rounding error is relative to the peak).  The FFT here
-// therefore runs in float64 -- the MI355X vector ALU executes v_fma_f64 at half the float32 rate -- and only the
+// therefore runs in float64 -- one v_fma_f64 per 4 cycles and wave on the MI355X vector ALU, the rate of unpacked float32 --
+// and only the
 // window product (as in the reference), |X| -> log1p and the flux run in float32.
 //
 // Design (one 64-lane wavefront per frame, frames_per_wave consecutive frames per wave):
@@ -23,8 +24,10 @@
 //    Z[l + 64 j] (j in {0,1,4,5,8,9,12,13}) a lane reads the groups that produce Z[1024 - l - 64 j], so the real-FFT
 //    unpack finds both operands of a bin pair in its own registers (no cross-lane traffic after pass 3);
 //  * wave reductions (flux, mean|x|, band maxima) are DPP row operations, not LDS round trips;
-//  * lane-dependent twiddles W1024^(l k1) and W2048^(l + 64 j) are powers / constant multiples of one per-lane
-//    base value held in registers; the small W64^(r q) table and the window are staged in LDS once per workgroup;
+//  * the tables (window, W1024^(l k1), W64^(r q), the log table) are staged in LDS once per workgroup; the lane's 16 window
+//    pairs, its twelve W64^(r q) factors (applied behind the second transpose) and its unpack twiddles 0.5 W2048^l W32^j
+//    then live in registers across the frame loop, W1024^(l k1) is read from LDS per frame (one ds_read_b128 each);
+//  * the constant twiddles inside the 16-point DFTs are folded into the additions that consume them (radix4_tw1/2/3);
 //  * a wave walks consecutive frames, so the previous 1024-sample block (Analyzer.buffer[:1024]) and the
 //    previous magnitudes (Analyzer.prev_mag) stay in registers; HBM sees every audio sample once per chunk
 //    (plus a 2-block halo per chunk) and every output once;

@@ -155,6 +155,26 @@ def test_time_shards_equal_unsharded(eng):
         assert np.array_equal(_np(psc.phase), _np(fsc.phase)[a:b])
 
 
+@pytest.mark.parametrize("sr,fps,ch", [(48000, 60, 2), (44100, 60, 2), (44100, 30, 2), (48000, 60, 1)])
+def test_flux_of_every_frame_follows_from_the_stored_spectra(eng, sr, fps, ch):
+    """The raw flux of frame f is sum(max(|X_f| - |X_f-1|, 0)); |X_f-1| comes from the wave's registers, and at the start of
+    every chunk of frames from a replayed halo frame.  Recomputed from the kernel's own stored log-spectra (expm1: 1e-7
+    relative) it must agree for EVERY frame -- a chunk whose halo hands wrong magnitudes on (in round 3 an asm move read the
+    result of v_sqrt_f32 one wait state early, in the halo code only) shows up as one frame in every frames-per-wave, 0.5 - 2 %
+    off.  Short tracks run at four frames per wave, so a 6 s track has 90 chunk starts."""
+    from aurora_amd import synth
+    audio = synth.pink(sr * 6 + 123, ch, seed=23)
+    track = eng.upload_track(audio, sr, fps)
+    for kw in ({}, {"want_samples": True}, {"want_bandmax": True}):
+        an = eng.analyze(track, **kw)
+        mag = np.expm1(_np(an.logspec).astype(np.float64))
+        prev = np.vstack([np.zeros((1, mag.shape[1])), mag[:-1]])
+        want = np.maximum(mag - prev, 0.0).sum(axis=1)
+        got = _np(an.flux_sum).astype(np.float64)
+        rel = np.abs(got - want) / np.maximum(want, 1e-6)
+        assert rel.max() < 1e-4, (kw, int(rel.argmax()), float(rel.max()))
+
+
 def test_scan_curves_and_state(eng):
     from aurora_amd import _lib
     import torch
